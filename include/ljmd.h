@@ -1,0 +1,190 @@
+/*
+ * ljmd.h -- C ABI of libljmd.so: the MI355X (gfx950) drop-in for the reference's
+ * Lennard-Jones force/energy + velocity-Verlet hot path.
+ *
+ * The reference (Ledicia/Molecular-Dynamics-Simulation---Lennard-Jones-monoatomic-fluid)
+ * has no FFI layer; its operator boundary is two Fortran module procedures
+ *     compute_lj_potential_energy(params, state, epot, d_epot, dd_epot)
+ *                                        scripts/physics/lj_potential_energy.f90:46
+ *     verlet_step(params, state, epot, ekin, d_epot, dd_epot)
+ *                                        scripts/physics/verlet.f90:41
+ * plus the caller-side per-step unwrapped-coordinate update
+ *                                        scripts/md_simulation_program.f90:339-353.
+ * Derived types with allocatable components are not bind(C)-interoperable, so the
+ * arrays cross as raw `double*` (c_loc(state%rx) ...) and the scalars by value.
+ * INTEGRATION.md shows the ISO_C_BINDING stub that binds each entry point.
+ *
+ * Conventions
+ *   - every function returns LJMD_OK (0) or a negative ljmd_status; the text of the
+ *     last error is available from ljmd_last_error() (the Fortran shim turns a
+ *     non-zero status into `stop 'ljmd: ...'`, the reference's own convention,
+ *     e.g. lj_potential_energy.f90:77-82).
+ *   - all arrays are fp64, length n, structure-of-arrays, 0-based in C.
+ *   - one handle = one simulation on one GPU; a handle is not thread-safe
+ *     (the reference is serial), independent handles may coexist.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with LJMD_ERR_NO_DEVICE.
+ */
+#ifndef LJMD_H
+#define LJMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ljmd ljmd_t;
+
+typedef enum ljmd_status {
+    LJMD_OK = 0,
+    LJMD_ERR_INVALID_ARG = -1, /* a guard of md_types.f90:143-161 / lj_potential_energy.f90:77-82 failed */
+    LJMD_ERR_NO_DEVICE = -2,   /* no HIP device / device code cannot run */
+    LJMD_ERR_HIP = -3,         /* a HIP runtime call failed */
+    LJMD_ERR_STATE = -4,       /* call sequence error (e.g. step before set_state) */
+    LJMD_ERR_ALLOC = -5
+} ljmd_status;
+
+/* precision_mode for ljmd_create */
+#define LJMD_PRECISION_FP64 0       /* all arithmetic fp64 (BASELINE configs 1-4)            */
+#define LJMD_PRECISION_FP32_FORCE 1 /* fp32 pair arithmetic, fp64 accumulation + integrator  */
+
+/* Which state array: argument of ljmd_device_ptr / selectors of get_state. */
+enum { LJMD_R = 0, LJMD_RU = 1, LJMD_V = 2, LJMD_A = 3 };
+
+/* ---- library-level ------------------------------------------------------ */
+
+/* "ljmd <version> gfx950"; never NULL. */
+const char *ljmd_version(void);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int32_t ljmd_device_count(void);
+/* Text of the most recent error on this handle (h == NULL: the most recent
+ * error of a failed ljmd_create or of a stateless call on this thread). */
+const char *ljmd_last_error(const ljmd_t *h);
+
+/* ---- handle lifecycle --------------------------------------------------- */
+
+/*
+ * Creates an engine for n particles in a cubic box.  Replaces init_params +
+ * compute_derived_params + init_state (scripts/base/md_types.f90:105-201): the
+ * derived constants 1/L, L**3, rc*rc, 0.5*dt, (0.5*dt)*dt are computed on the
+ * host exactly as written there, and the same guards apply (n > 0, L > 0,
+ * rc > 0, rc < L/2, dt > 0) -> LJMD_ERR_INVALID_ARG.
+ * rank/n_ranks select the contiguous particle shard [rank*n/n_ranks,
+ * (rank+1)*n/n_ranks) this engine integrates and owns pair rows for (SURVEY
+ * 8(e)); n_ranks = 1 is the ordinary single-GPU engine.  n must be divisible
+ * by n_ranks.
+ */
+int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc,
+                int32_t precision_mode, int32_t device, int32_t rank, int32_t n_ranks);
+void ljmd_destroy(ljmd_t *h);
+
+/* ---- state transfer ------------------------------------------------------ */
+
+/* Host -> HBM.  Replaces read_rv_init + `ru <- r` (md_simulation_program.f90:221-231).
+ * Accelerations are zeroed (init_state semantics). All six pointers required. */
+int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz,
+                   const double *vx, const double *vy, const double *vz);
+/* Host -> HBM for a / ru, so that a caller can resume from a full rva.dat snapshot or
+ * run verlet_step on caller-owned accelerations (strict drop-in mode). NULL = keep. */
+int ljmd_set_accel(ljmd_t *h, const double *ax, const double *ay, const double *az);
+int ljmd_set_unwrapped(ljmd_t *h, const double *ux, const double *uy, const double *uz);
+/* HBM -> host; any pointer may be NULL (skipped).  r, ru, v, a as in the four
+ * records of an rva.dat snapshot (md_simulation_program.f90:384-387). */
+int ljmd_get_state(ljmd_t *h, double *rx, double *ry, double *rz,
+                   double *ux, double *uy, double *uz,
+                   double *vx, double *vy, double *vz,
+                   double *ax, double *ay, double *az);
+
+/* ---- the hot path -------------------------------------------------------- */
+
+/*
+ * = compute_lj_potential_energy (lj_potential_energy.f90:46-225) on the resident
+ * positions: overwrites the resident accelerations, returns epot, d_epot, dd_epot
+ * including the x4 / x24 prefactors (:188-193) and the tail corrections (:205-223).
+ */
+int ljmd_compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot);
+
+/*
+ * = nsteps x { verlet_step (verlet.f90:41-97) ; unwrapped update
+ * (md_simulation_program.f90:339-353) } with no host synchronisation inside.
+ * Requires valid resident accelerations (ljmd_compute_forces or ljmd_set_accel
+ * first, as the reference's drivers do at md_simulation_program.f90:236).
+ * epot/ekin/d_epot/dd_epot: each NULL or an array of nsteps doubles receiving the
+ * value after every step.
+ */
+int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps,
+                      double *epot, double *ekin, double *d_epot, double *dd_epot);
+
+/* Kinetic energy of the resident velocities, one fused sum as at
+ * md_simulation_program.f90:238-240 (t = 0 only). */
+int ljmd_kinetic_energy(ljmd_t *h, double *ekin);
+
+/* ---- stateless drop-ins (what the Fortran shim modules bind) ------------- */
+
+/*
+ * Exact signature-level replacement of compute_lj_potential_energy: host arrays in,
+ * host arrays out, the params fields passed by value.  Internally keeps one cached
+ * engine per (n, L, rc) on device 0.
+ */
+int ljmd_compute_lj_potential_energy(int32_t n, double box_length, double rc,
+                                     const double *rx, const double *ry, const double *rz,
+                                     double *ax, double *ay, double *az,
+                                     double *epot, double *d_epot, double *dd_epot);
+/* Exact replacement of verlet_step: the nine state arrays are updated in place. */
+int ljmd_verlet_step(int32_t n, double box_length, double dt, double rc,
+                     double *rx, double *ry, double *rz,
+                     double *vx, double *vy, double *vz,
+                     double *ax, double *ay, double *az,
+                     double *epot, double *ekin, double *d_epot, double *dd_epot);
+/* Frees the cached engines of the stateless entry points. */
+void ljmd_stateless_reset(void);
+
+/* ---- multi-GPU split-phase API (one process per GPU) -------- */
+
+/* [i0, i1) = particle rows this engine owns. */
+int ljmd_shard_range(const ljmd_t *h, int32_t *i0, int32_t *i1);
+/*
+ * Device address of the exchange buffer holding ALL n positions in shard-blocked
+ * SoA order: block g (g = 0..n_ranks-1) is x[S] y[S] z[S] of rank g's particles,
+ * S = n/n_ranks.  Rank g's own block is at offset g*3*S doubles, so one in-place
+ * RCCL all-gather of 3*S doubles per rank refreshes it.  (n_ranks = 1: plain SoA.)
+ */
+void *ljmd_exchange_buffer(ljmd_t *h, int64_t *n_doubles_total, int64_t *own_offset_doubles,
+                           int64_t *own_count_doubles);
+/* Device address of one resident state array (LJMD_R..LJMD_A, axis 0..2), length
+ * = shard size; for zero-copy views (e.g. torch via __cuda_array_interface__). */
+void *ljmd_device_ptr(ljmd_t *h, int32_t which, int32_t axis);
+/* The HIP stream (hipStream_t) all of this handle's kernels are launched on. */
+void *ljmd_stream(ljmd_t *h);
+/* Phase 1: drift + wrap + half-kick + unwrapped update of the owned shard; the new
+ * positions are written into the own block of the exchange buffer. */
+int ljmd_step_begin(ljmd_t *h);
+/* Phase 2 (after the all-gather): pair forces for the owned rows against all n
+ * positions, second half-kick, per-rank partial sums appended to the scalar ring. */
+int ljmd_step_finish(ljmd_t *h);
+/* Pair forces only (t = 0 evaluation) on the exchange buffer contents. */
+int ljmd_forces_partial(ljmd_t *h);
+/*
+ * Copies out the raw per-rank partial sums of the last `nsteps` finished phases:
+ * partial[4*k + {0,1,2,3}] = { sum u^-12 , sum u^-6 , sum |v|^2 contributions (x,y,z
+ * added) , 0 } -- see ljmd_combine_scalars.  Resets the ring.
+ */
+int ljmd_read_partials(ljmd_t *h, int32_t nsteps, double *partial);
+/* Host-side, deterministic: combines the n_ranks partial records of ONE step (rank
+ * order) into epot, ekin, d_epot, dd_epot incl. prefactors and tail corrections. */
+int ljmd_combine_scalars(const ljmd_t *h, const double *partials_by_rank, int32_t n_ranks,
+                         double *epot, double *ekin, double *d_epot, double *dd_epot);
+
+/* ---- measurement --------------------------------------------------------- */
+
+/* Average device time in milliseconds of the pair-force kernel over the launches
+ * since the last call (HIP events on the handle's own stream); *launches = count.
+ * Timing is armed by ljmd_profile_enable(h, 1). */
+int ljmd_profile_enable(ljmd_t *h, int32_t on);
+int ljmd_profile_read(ljmd_t *h, double *force_ms_avg, double *integrate_ms_avg, int32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LJMD_H */

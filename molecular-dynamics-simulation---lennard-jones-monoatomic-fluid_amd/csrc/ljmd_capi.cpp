@@ -1,0 +1,716 @@
+// ljmd_capi.cpp -- host side of libljmd.so: the C ABI declared in include/ljmd.h.
+//
+// Owns the HBM-resident simulation state and sequences the gfx950 kernels of
+// ljmd_kernels.hip on one HIP stream.  There is no CPU compute path in this
+// library: without a HIP device every compute entry point returns
+// LJMD_ERR_NO_DEVICE.
+#include "ljmd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ljmd_internal.h"
+
+using namespace ljmdk;
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+constexpr unsigned kRingCap = 4096;     // per-step partial records kept on the device
+constexpr int kTargetWorkgroups = 2048; // >> 256 CUs (8 per CU) for the pair kernel
+constexpr int kMaxProfiledLaunches = 4096;
+
+// md_types.f90:22
+constexpr double kPi = 3.1415926535897932384626433832795;
+
+struct EventQuad {
+    hipEvent_t e[4];
+};
+
+}  // namespace
+
+struct ljmd {
+    // ---- parameters (type(sim_params), md_types.f90:27-50) ----
+    int n = 0, shard = 0, rank = 0, n_ranks = 1, device = 0, mode = 0;
+    double L = 0, invL = 0, volume = 0, rc = 0, rc2 = 0, dt = 0, dt_half = 0, dt_sq_half = 0;
+    double tail_e = 0, tail_d = 0, tail_dd = 0;
+    bool rc_allows_fast_mic = false;  // rc <= (1 - 1e-9) * L/2
+    bool positions_compact = false;   // coordinate spread < 2.4 L (always true after a wrap)
+    bool have_state = false, have_accel = false;
+
+    hipStream_t stream = nullptr;
+    // ---- HBM-resident state ----
+    double *d_pos = nullptr;      // [n_ranks][3][shard]  exchange buffer (all positions)
+    double *d_ru = nullptr;       // [3][shard]
+    double *d_v = nullptr;        // [3][shard]
+    double *d_a = nullptr;        // [3][shard]
+    double *d_slab = nullptr;     // [nslab][3][shard]
+    double *d_wg_part = nullptr;  // [n_wg][2]
+    double *d_ke_part = nullptr;  // [n_ke][3]
+    double *d_ring = nullptr;     // [kRingCap][kPartialStride]
+    unsigned *d_ring_pos = nullptr;
+    unsigned ring_consumed = 0;   // host mirror: records already read back
+    unsigned ring_issued = 0;     // host mirror: finalize launches issued
+    int nslab = 1, chunk = 0, n_wg = 0, n_ke = 0;
+    dim3 pair_grid;
+
+    double *h_stage = nullptr;    // pinned, 3*n doubles
+    double *h_ring = nullptr;     // pinned, kRingCap records
+
+    bool profiling = false;
+    std::vector<EventQuad> ev_pool;
+    size_t ev_used = 0;
+
+    std::string err;
+};
+
+namespace {
+
+int fail(ljmd_t *h, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    if (h) h->err = buf;
+    return code;
+}
+
+#define LJMD_HIP(h, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((h), LJMD_ERR_HIP, "%s failed: %s (%s:%d)", #call,                  \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+double *own_block(ljmd_t *h) { return h->d_pos + (size_t)h->rank * 3 * h->shard; }
+
+PairArgs pair_args(ljmd_t *h)
+{
+    PairArgs a;
+    a.pos = h->d_pos;
+    a.slab = h->d_slab;
+    a.wg_part = h->d_wg_part;
+    a.n = h->n;
+    a.shard = h->shard;
+    a.rank = h->rank;
+    a.row0 = h->rank * h->shard;
+    a.rows = h->shard;
+    a.chunk = h->chunk;
+    a.L = h->L;
+    a.invL = h->invL;
+    a.rc2 = h->rc2;
+    return a;
+}
+
+IntegrateArgs integrate_args(ljmd_t *h)
+{
+    IntegrateArgs a;
+    a.r = own_block(h);
+    a.ru = h->d_ru;
+    a.v = h->d_v;
+    a.a = h->d_a;
+    a.slab = h->d_slab;
+    a.ke_part = h->d_ke_part;
+    a.rows = h->shard;
+    a.shard = h->shard;
+    a.nslab = h->nslab;
+    a.L = h->L;
+    a.invL = h->invL;
+    a.dt = h->dt;
+    a.dt_half = h->dt_half;
+    a.dt_sq_half = h->dt_sq_half;
+    return a;
+}
+
+FinalizeArgs finalize_args(ljmd_t *h, bool with_ke)
+{
+    FinalizeArgs a;
+    a.wg_part = h->d_wg_part;
+    a.ke_part = h->d_ke_part;
+    a.ring = h->d_ring;
+    a.ring_pos = h->d_ring_pos;
+    a.n_wg = h->n_wg;
+    a.n_ke = with_ke ? h->n_ke : 0;
+    a.ring_cap = kRingCap;
+    return a;
+}
+
+EventQuad *next_events(ljmd_t *h)
+{
+    if (!h->profiling || h->ev_used >= (size_t)kMaxProfiledLaunches) return nullptr;
+    if (h->ev_used == h->ev_pool.size()) {
+        EventQuad q;
+        for (auto &e : q.e)
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        h->ev_pool.push_back(q);
+    }
+    return &h->ev_pool[h->ev_used++];
+}
+
+bool fast_mic(const ljmd_t *h) { return h->rc_allows_fast_mic && h->positions_compact; }
+
+// forces on the owned rows from the exchange buffer; a <- 24 * sum(slabs)
+int enqueue_forces(ljmd_t *h, bool kick, EventQuad *q)
+{
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[1], h->stream));
+    LJMD_HIP(h, launch_pair_rows(pair_args(h), fast_mic(h), h->pair_grid, h->stream));
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
+    LJMD_HIP(h, launch_reduce_kick(integrate_args(h), kick, h->stream));
+    LJMD_HIP(h, launch_finalize(finalize_args(h, kick), h->stream));
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[3], h->stream));
+    h->ring_issued++;
+    h->have_accel = true;
+    return LJMD_OK;
+}
+
+int enqueue_drift(ljmd_t *h, EventQuad *q)
+{
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
+    LJMD_HIP(h, launch_drift_kick(integrate_args(h), h->stream));
+    h->positions_compact = true;  // freshly wrapped into [0, L]
+    return LJMD_OK;
+}
+
+// Reads back the not-yet-consumed partial records (at most kRingCap) into h_ring.
+int fetch_ring(ljmd_t *h, unsigned count)
+{
+    if (count > h->ring_issued - h->ring_consumed)
+        return fail(h, LJMD_ERR_STATE, "requested %u step records but only %u are pending", count,
+                    h->ring_issued - h->ring_consumed);
+    // skip older unread records (caller asked for the LAST `count`)
+    h->ring_consumed = h->ring_issued - count;
+    unsigned done = 0;
+    while (done < count) {
+        const unsigned pos = (h->ring_consumed + done) % kRingCap;
+        const unsigned run = std::min(count - done, kRingCap - pos);
+        LJMD_HIP(h, hipMemcpyAsync(h->h_ring + (size_t)done * kPartialStride,
+                                   h->d_ring + (size_t)pos * kPartialStride,
+                                   (size_t)run * kPartialStride * sizeof(double),
+                                   hipMemcpyDeviceToHost, h->stream));
+        done += run;
+    }
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    h->ring_consumed = h->ring_issued;
+    return LJMD_OK;
+}
+
+void combine_one(const ljmd_t *h, const double *recs, int n_ranks, double *epot, double *ekin,
+                 double *d_epot, double *dd_epot)
+{
+    double s12 = 0, s6 = 0, kx = 0, ky = 0, kz = 0;
+    for (int g = 0; g < n_ranks; ++g) {  // fixed rank order
+        const double *r = recs + (size_t)g * kPartialStride;
+        s12 += r[0];
+        s6 += r[1];
+        kx += r[2];
+        ky += r[3];
+        kz += r[4];
+    }
+    // every unordered pair was visited twice by the full-matrix rows -> exact halving
+    s12 *= 0.5;
+    s6 *= 0.5;
+    if (epot) *epot = 4.0 * (s12 - s6) + h->tail_e;                   // :140,:188,:221
+    if (d_epot) *d_epot = 24.0 * (-2.0 * s12 + s6) + h->tail_d;       // :143,:177,:192,:222
+    if (dd_epot) *dd_epot = 24.0 * (26.0 * s12 - 7.0 * s6) + h->tail_dd;  // :178,:193,:223
+    if (ekin) *ekin = 0.5 * (kx + ky + kz);                           // verlet.f90:93-95
+}
+
+void release(ljmd_t *h)
+{
+    if (!h) return;
+    if (h->device >= 0) (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &q : h->ev_pool)
+        for (auto &e : q.e) (void)hipEventDestroy(e);
+    (void)hipFree(h->d_pos);
+    (void)hipFree(h->d_ru);
+    (void)hipFree(h->d_v);
+    (void)hipFree(h->d_a);
+    (void)hipFree(h->d_slab);
+    (void)hipFree(h->d_wg_part);
+    (void)hipFree(h->d_ke_part);
+    (void)hipFree(h->d_ring);
+    (void)hipFree(h->d_ring_pos);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_ring) (void)hipHostFree(h->h_ring);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char *ljmd_version(void) { return "ljmd 0.1.0 gfx950"; }
+
+int32_t ljmd_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+const char *ljmd_last_error(const ljmd_t *h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc,
+                int32_t precision_mode, int32_t device, int32_t rank, int32_t n_ranks)
+{
+    if (!out) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: out is NULL");
+    *out = nullptr;
+    // guards of md_types.f90:143-161 and allocate_state :192
+    if (n <= 0) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: n must be > 0");
+    if (!(box_length > 0.0)) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: box_length must be > 0");
+    if (!(rc > 0.0)) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: rc must be > 0");
+    if (rc >= 0.5 * box_length)
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: rc must be < L/2 (minimum image convention)");
+    if (!(dt > 0.0)) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: dt must be > 0");
+    if (precision_mode != LJMD_PRECISION_FP64)
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: precision_mode %d not available", precision_mode);
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: bad rank %d of %d", rank, n_ranks);
+    if (n % n_ranks != 0)
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: n=%d not divisible by n_ranks=%d", n, n_ranks);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LJMD_ERR_NO_DEVICE, "ljmd_create: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: device %d out of range (0..%d)", device, ndev - 1);
+
+    ljmd_t *h = new (std::nothrow) ljmd;
+    if (!h) return fail(nullptr, LJMD_ERR_ALLOC, "ljmd_create: out of host memory");
+    h->n = n;
+    h->n_ranks = n_ranks;
+    h->rank = rank;
+    h->shard = n / n_ranks;
+    h->device = device;
+    h->mode = precision_mode;
+    // compute_derived_params, md_types.f90:137-159, same expressions
+    h->L = box_length;
+    h->invL = 1.0 / box_length;
+    h->volume = box_length * box_length * box_length;
+    h->rc = rc;
+    h->rc2 = rc * rc;
+    h->dt = dt;
+    h->dt_half = 0.5 * dt;
+    h->dt_sq_half = h->dt_half * dt;
+    {   // tail corrections, lj_potential_energy.f90:205-223
+        const double npd = (double)n;
+        const double rc3 = (rc * rc) * rc;
+        const double rc6 = ((rc * rc) * (rc * rc)) * (rc * rc);
+        const double tf = 8.0 * kPi * (npd * npd) / (h->volume * rc3);
+        h->tail_e = tf * ((1.0 / (3.0 * rc6)) - 1.0) / 3.0;
+        h->tail_d = 2.0 * tf * (-2.0 / (3.0 * rc6) + 1.0);
+        h->tail_dd = 2.0 * tf * (26.0 / (3.0 * rc6) - 7.0);
+    }
+    h->rc_allows_fast_mic = rc <= (1.0 - 1e-9) * 0.5 * box_length;
+
+    // launch geometry of the pair kernel: rows x j-chunks >= kTargetWorkgroups
+    const int row_tiles = (h->shard + kBlock - 1) / kBlock;
+    int nslab = (kTargetWorkgroups + row_tiles - 1) / row_tiles;
+    nslab = std::max(1, std::min(nslab, (n + 63) / 64));
+    h->chunk = (n + nslab - 1) / nslab;
+    h->chunk = ((h->chunk + 7) / 8) * 8;
+    h->nslab = (n + h->chunk - 1) / h->chunk;
+    h->pair_grid = dim3(row_tiles, h->nslab);
+    h->n_wg = row_tiles * h->nslab;
+    h->n_ke = row_tiles;
+
+    int rc_ = LJMD_OK;
+    auto body = [&]() -> int {
+        LJMD_HIP(h, hipSetDevice(device));
+        LJMD_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        const size_t S3 = 3 * (size_t)h->shard * sizeof(double);
+        LJMD_HIP(h, hipMalloc(&h->d_pos, 3 * (size_t)n * sizeof(double)));
+        LJMD_HIP(h, hipMalloc(&h->d_ru, S3));
+        LJMD_HIP(h, hipMalloc(&h->d_v, S3));
+        LJMD_HIP(h, hipMalloc(&h->d_a, S3));
+        LJMD_HIP(h, hipMalloc(&h->d_slab, S3 * h->nslab));
+        LJMD_HIP(h, hipMalloc(&h->d_wg_part, 2 * (size_t)h->n_wg * sizeof(double)));
+        LJMD_HIP(h, hipMalloc(&h->d_ke_part, 3 * (size_t)h->n_ke * sizeof(double)));
+        LJMD_HIP(h, hipMalloc(&h->d_ring, (size_t)kRingCap * kPartialStride * sizeof(double)));
+        LJMD_HIP(h, hipMalloc(&h->d_ring_pos, sizeof(unsigned)));
+        LJMD_HIP(h, hipMemsetAsync(h->d_ring_pos, 0, sizeof(unsigned), h->stream));
+        LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, S3, h->stream));
+        LJMD_HIP(h, hipMemsetAsync(h->d_ke_part, 0, 3 * (size_t)h->n_ke * sizeof(double), h->stream));
+        LJMD_HIP(h, hipHostMalloc(&h->h_stage, 3 * (size_t)n * sizeof(double), hipHostMallocDefault));
+        LJMD_HIP(h, hipHostMalloc(&h->h_ring, (size_t)kRingCap * kPartialStride * sizeof(double),
+                                  hipHostMallocDefault));
+        LJMD_HIP(h, hipStreamSynchronize(h->stream));
+        return LJMD_OK;
+    };
+    rc_ = body();
+    if (rc_ != LJMD_OK) {
+        g_last_error = h->err;
+        release(h);
+        return rc_;
+    }
+    *out = h;
+    return LJMD_OK;
+}
+
+void ljmd_destroy(ljmd_t *h) { release(h); }
+
+// ---- state transfer --------------------------------------------------------
+
+static int upload_shard3(ljmd_t *h, double *dst, const double *x, const double *y, const double *z,
+                         bool global_arrays)
+{
+    // x,y,z: length n (global_arrays) or shard; packs [3][shard] of the owned rows
+    const size_t S = h->shard, off = global_arrays ? (size_t)h->rank * S : 0;
+    std::memcpy(h->h_stage, x + off, S * sizeof(double));
+    std::memcpy(h->h_stage + S, y + off, S * sizeof(double));
+    std::memcpy(h->h_stage + 2 * S, z + off, S * sizeof(double));
+    LJMD_HIP(h, hipMemcpyAsync(dst, h->h_stage, 3 * S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
+    return LJMD_OK;
+}
+
+int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz,
+                   const double *vx, const double *vy, const double *vz)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_set_state: NULL handle");
+    if (!rx || !ry || !rz || !vx || !vy || !vz)
+        return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_set_state: NULL array");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    const size_t S = h->shard;
+    // all n positions into the exchange buffer, shard-blocked; track the coordinate spread
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const double *src[3] = {rx, ry, rz};
+    bool finite = true;
+    for (int g = 0; g < h->n_ranks; ++g)
+        for (int ax = 0; ax < 3; ++ax) {
+            double *dst = h->h_stage + ((size_t)g * 3 + ax) * S;
+            const double *s = src[ax] + (size_t)g * S;
+            for (size_t i = 0; i < S; ++i) {
+                const double x = s[i];
+                dst[i] = x;
+                lo[ax] = std::min(lo[ax], x);
+                hi[ax] = std::max(hi[ax], x);
+                finite = finite && std::isfinite(x);
+            }
+        }
+    h->positions_compact = finite;
+    for (int ax = 0; ax < 3; ++ax)
+        if (!(hi[ax] - lo[ax] < 2.4 * h->L)) h->positions_compact = false;
+    LJMD_HIP(h, hipMemcpyAsync(h->d_pos, h->h_stage, 3 * (size_t)h->n * sizeof(double),
+                               hipMemcpyHostToDevice, h->stream));
+    // ru <- r (md_simulation_program.f90:229-231), own shard
+    LJMD_HIP(h, hipMemcpyAsync(h->d_ru, own_block(h), 3 * S * sizeof(double), hipMemcpyDeviceToDevice,
+                               h->stream));
+    LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, 3 * S * sizeof(double), h->stream));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    int rc_ = upload_shard3(h, h->d_v, vx, vy, vz, true);
+    if (rc_ != LJMD_OK) return rc_;
+    h->have_state = true;
+    h->have_accel = false;
+    return LJMD_OK;
+}
+
+int ljmd_set_accel(ljmd_t *h, const double *ax, const double *ay, const double *az)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_set_accel: NULL handle");
+    if (!ax || !ay || !az) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_set_accel: NULL array");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    int rc_ = upload_shard3(h, h->d_a, ax, ay, az, true);
+    if (rc_ == LJMD_OK) h->have_accel = true;
+    return rc_;
+}
+
+int ljmd_set_unwrapped(ljmd_t *h, const double *ux, const double *uy, const double *uz)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_set_unwrapped: NULL handle");
+    if (!ux || !uy || !uz) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_set_unwrapped: NULL array");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    return upload_shard3(h, h->d_ru, ux, uy, uz, true);
+}
+
+int ljmd_get_state(ljmd_t *h, double *rx, double *ry, double *rz, double *ux, double *uy, double *uz,
+                   double *vx, double *vy, double *vz, double *ax, double *ay, double *az)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_get_state: NULL handle");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_get_state: no state has been set");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    const size_t S = h->shard;
+    const double *srcs[4] = {own_block(h), h->d_ru, h->d_v, h->d_a};
+    double *dsts[4][3] = {{rx, ry, rz}, {ux, uy, uz}, {vx, vy, vz}, {ax, ay, az}};
+    for (int w = 0; w < 4; ++w) {
+        if (!dsts[w][0] && !dsts[w][1] && !dsts[w][2]) continue;
+        LJMD_HIP(h, hipMemcpyAsync(h->h_stage, srcs[w], 3 * S * sizeof(double), hipMemcpyDeviceToHost,
+                                   h->stream));
+        LJMD_HIP(h, hipStreamSynchronize(h->stream));
+        for (int k = 0; k < 3; ++k)
+            if (dsts[w][k]) std::memcpy(dsts[w][k], h->h_stage + k * S, S * sizeof(double));
+    }
+    return LJMD_OK;
+}
+
+// ---- hot path ----------------------------------------------------------------
+
+int ljmd_compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_compute_forces: NULL handle");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_compute_forces: no state has been set");
+    if (h->n_ranks != 1)
+        return fail(h, LJMD_ERR_STATE, "ljmd_compute_forces: sharded engine; use ljmd_forces_partial");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    EventQuad *q = next_events(h);
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
+    int rc_ = enqueue_forces(h, false, q);
+    if (rc_ != LJMD_OK) return rc_;
+    rc_ = fetch_ring(h, 1);
+    if (rc_ != LJMD_OK) return rc_;
+    combine_one(h, h->h_ring, 1, epot, nullptr, d_epot, dd_epot);
+    return LJMD_OK;
+}
+
+int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, double *d_epot,
+                      double *dd_epot)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_verlet_steps: NULL handle");
+    if (nsteps < 0) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_verlet_steps: nsteps < 0");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_verlet_steps: no state has been set");
+    if (!h->have_accel)
+        return fail(h, LJMD_ERR_STATE,
+                    "ljmd_verlet_steps: accelerations not initialised (call ljmd_compute_forces first)");
+    if (h->n_ranks != 1)
+        return fail(h, LJMD_ERR_STATE, "ljmd_verlet_steps: sharded engine; use ljmd_step_begin/finish");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    int done = 0;
+    while (done < nsteps) {
+        const int batch = std::min<int>(nsteps - done, (int)kRingCap);
+        for (int s = 0; s < batch; ++s) {
+            EventQuad *q = next_events(h);
+            int rc_ = enqueue_drift(h, q);
+            if (rc_ != LJMD_OK) return rc_;
+            rc_ = enqueue_forces(h, true, q);
+            if (rc_ != LJMD_OK) return rc_;
+        }
+        int rc_ = fetch_ring(h, (unsigned)batch);
+        if (rc_ != LJMD_OK) return rc_;
+        for (int s = 0; s < batch; ++s)
+            combine_one(h, h->h_ring + (size_t)s * kPartialStride, 1, epot ? epot + done + s : nullptr,
+                        ekin ? ekin + done + s : nullptr, d_epot ? d_epot + done + s : nullptr,
+                        dd_epot ? dd_epot + done + s : nullptr);
+        done += batch;
+    }
+    return LJMD_OK;
+}
+
+int ljmd_kinetic_energy(ljmd_t *h, double *ekin)
+{
+    if (!h || !ekin) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_kinetic_energy: NULL argument");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_kinetic_energy: no state has been set");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    LJMD_HIP(h, launch_kinetic_fused(integrate_args(h), h->stream));
+    std::vector<double> part(3 * (size_t)h->n_ke);
+    LJMD_HIP(h, hipMemcpyAsync(part.data(), h->d_ke_part, part.size() * sizeof(double),
+                               hipMemcpyDeviceToHost, h->stream));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    double s = 0.0;
+    for (int b = 0; b < h->n_ke; ++b) s += part[3 * (size_t)b];
+    *ekin = 0.5 * s;  // per-rank partial when sharded
+    return LJMD_OK;
+}
+
+// ---- multi-GPU split phase ---------------------------------------------------
+
+int ljmd_shard_range(const ljmd_t *h, int32_t *i0, int32_t *i1)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_shard_range: NULL handle");
+    if (i0) *i0 = h->rank * h->shard;
+    if (i1) *i1 = (h->rank + 1) * h->shard;
+    return LJMD_OK;
+}
+
+void *ljmd_exchange_buffer(ljmd_t *h, int64_t *n_total, int64_t *own_off, int64_t *own_cnt)
+{
+    if (!h) return nullptr;
+    if (n_total) *n_total = 3 * (int64_t)h->n;
+    if (own_off) *own_off = (int64_t)h->rank * 3 * h->shard;
+    if (own_cnt) *own_cnt = 3 * (int64_t)h->shard;
+    return h->d_pos;
+}
+
+void *ljmd_device_ptr(ljmd_t *h, int32_t which, int32_t axis)
+{
+    if (!h || axis < 0 || axis > 2) return nullptr;
+    double *base = nullptr;
+    switch (which) {
+        case LJMD_R: base = own_block(h); break;
+        case LJMD_RU: base = h->d_ru; break;
+        case LJMD_V: base = h->d_v; break;
+        case LJMD_A: base = h->d_a; break;
+        default: return nullptr;
+    }
+    return base + (size_t)axis * h->shard;
+}
+
+void *ljmd_stream(ljmd_t *h) { return h ? (void *)h->stream : nullptr; }
+
+int ljmd_step_begin(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_step_begin: NULL handle");
+    if (!h->have_state || !h->have_accel)
+        return fail(h, LJMD_ERR_STATE, "ljmd_step_begin: state/accelerations not initialised");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    return enqueue_drift(h, nullptr);
+}
+
+int ljmd_step_finish(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_step_finish: NULL handle");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_step_finish: no state has been set");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    EventQuad *q = next_events(h);
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
+    return enqueue_forces(h, true, q);
+}
+
+int ljmd_forces_partial(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_forces_partial: NULL handle");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_forces_partial: no state has been set");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    return enqueue_forces(h, false, nullptr);
+}
+
+int ljmd_read_partials(ljmd_t *h, int32_t nsteps, double *partial)
+{
+    if (!h || !partial || nsteps < 0 || nsteps > (int)kRingCap)
+        return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_read_partials: bad argument");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    int rc_ = fetch_ring(h, (unsigned)nsteps);
+    if (rc_ != LJMD_OK) return rc_;
+    std::memcpy(partial, h->h_ring, (size_t)nsteps * kPartialStride * sizeof(double));
+    return LJMD_OK;
+}
+
+int ljmd_combine_scalars(const ljmd_t *h, const double *partials_by_rank, int32_t n_ranks, double *epot,
+                         double *ekin, double *d_epot, double *dd_epot)
+{
+    if (!h || !partials_by_rank || n_ranks < 1)
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_combine_scalars: bad argument");
+    combine_one(h, partials_by_rank, n_ranks, epot, ekin, d_epot, dd_epot);
+    return LJMD_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------
+
+int ljmd_profile_enable(ljmd_t *h, int32_t on)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_enable: NULL handle");
+    h->profiling = on != 0;
+    h->ev_used = 0;
+    return LJMD_OK;
+}
+
+int ljmd_profile_read(ljmd_t *h, double *force_ms_avg, double *integrate_ms_avg, int32_t *launches)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_read: NULL handle");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    double f = 0.0, g = 0.0;
+    for (size_t k = 0; k < h->ev_used; ++k) {
+        float ms = 0.f;
+        LJMD_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[k].e[1], h->ev_pool[k].e[2]));
+        f += ms;
+        LJMD_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[k].e[0], h->ev_pool[k].e[1]));
+        g += ms;
+        LJMD_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[k].e[2], h->ev_pool[k].e[3]));
+        g += ms;
+    }
+    const double cnt = h->ev_used ? (double)h->ev_used : 1.0;
+    if (force_ms_avg) *force_ms_avg = f / cnt;
+    if (integrate_ms_avg) *integrate_ms_avg = g / cnt;
+    if (launches) *launches = (int32_t)h->ev_used;
+    h->ev_used = 0;
+    return LJMD_OK;
+}
+
+// ---- stateless drop-ins ----------------------------------------------------------
+
+namespace {
+std::mutex g_cache_mutex;
+ljmd_t *g_cached = nullptr;
+
+int cached_engine(int32_t n, double L, double dt, double rc, ljmd_t **out)
+{
+    if (g_cached && (g_cached->n != n || g_cached->L != L || g_cached->rc != rc)) {
+        release(g_cached);
+        g_cached = nullptr;
+    }
+    if (!g_cached) {
+        int rc_ = ljmd_create(&g_cached, n, L, dt, rc, LJMD_PRECISION_FP64, 0, 0, 1);
+        if (rc_ != LJMD_OK) return rc_;
+    }
+    if (g_cached->dt != dt) {
+        if (!(dt > 0.0)) return fail(nullptr, LJMD_ERR_INVALID_ARG, "dt must be > 0");
+        g_cached->dt = dt;
+        g_cached->dt_half = 0.5 * dt;
+        g_cached->dt_sq_half = g_cached->dt_half * dt;
+    }
+    *out = g_cached;
+    return LJMD_OK;
+}
+}  // namespace
+
+int ljmd_compute_lj_potential_energy(int32_t n, double box_length, double rc, const double *rx,
+                                     const double *ry, const double *rz, double *ax, double *ay,
+                                     double *az, double *epot, double *d_epot, double *dd_epot)
+{
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    if (!rx || !ry || !rz || !ax || !ay || !az)  // lj_potential_energy.f90:82
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "compute_lj_potential_energy(): state arrays are not allocated.");
+    ljmd_t *h = nullptr;
+    int rc_ = cached_engine(n, box_length, 1.0, rc, &h);
+    if (rc_ != LJMD_OK) return rc_;
+    // velocities are irrelevant here; reuse the position arrays as dummies
+    if ((rc_ = ljmd_set_state(h, rx, ry, rz, rx, ry, rz)) != LJMD_OK) return rc_;
+    if ((rc_ = ljmd_compute_forces(h, epot, d_epot, dd_epot)) != LJMD_OK) return rc_;
+    rc_ = ljmd_get_state(h, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, ax, ay, az);
+    if (rc_ != LJMD_OK) g_last_error = h->err;
+    return rc_;
+}
+
+int ljmd_verlet_step(int32_t n, double box_length, double dt, double rc, double *rx, double *ry,
+                     double *rz, double *vx, double *vy, double *vz, double *ax, double *ay, double *az,
+                     double *epot, double *ekin, double *d_epot, double *dd_epot)
+{
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    if (!rx || !ry || !rz || !vx || !vy || !vz || !ax || !ay || !az)  // verlet.f90:52
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "verlet_step(): state arrays are not allocated.");
+    ljmd_t *h = nullptr;
+    int rc_ = cached_engine(n, box_length, dt, rc, &h);
+    if (rc_ != LJMD_OK) return rc_;
+    if ((rc_ = ljmd_set_state(h, rx, ry, rz, vx, vy, vz)) != LJMD_OK) return rc_;
+    if ((rc_ = ljmd_set_accel(h, ax, ay, az)) != LJMD_OK) return rc_;
+    if ((rc_ = ljmd_verlet_steps(h, 1, epot, ekin, d_epot, dd_epot)) != LJMD_OK) return rc_;
+    rc_ = ljmd_get_state(h, rx, ry, rz, nullptr, nullptr, nullptr, vx, vy, vz, ax, ay, az);
+    if (rc_ != LJMD_OK) g_last_error = h->err;
+    return rc_;
+}
+
+void ljmd_stateless_reset(void)
+{
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    if (g_cached) release(g_cached);
+    g_cached = nullptr;
+}
+
+}  // extern "C"

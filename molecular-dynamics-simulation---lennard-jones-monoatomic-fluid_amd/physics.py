@@ -1,0 +1,231 @@
+"""The reference's operator interface for the hot path, served by the HIP library.
+
+  compute_lj_potential_energy(params, state)   scripts/physics/lj_potential_energy.f90:46
+  verlet_step(params, state)                   scripts/physics/verlet.f90:41
+  minimum_image / wrap_positions               scripts/physics/geometry_pbc.f90:80,39 (host helpers)
+
+Both operators keep the reference's argument meaning: `state` is updated in place,
+the scalar outputs are returned as a tuple in the reference's argument order.  They
+go through the *stateless* C entry points (ljmd_compute_lj_potential_energy /
+ljmd_verlet_step), i.e. exactly what the Fortran shim modules bind.
+
+`Engine` is the resident-state interface (ljmd_create ... ljmd_verlet_steps): state
+stays in HBM between calls and only the per-step scalars come back.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import LjmdError, c_double_p
+from .md_types import SimParams, SimState
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _check_array(a, n: int, name: str) -> np.ndarray:
+    if a is None:
+        raise ValueError(f"{name} is not allocated")
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or a.ndim != 1 or a.shape[0] != n \
+            or not a.flags.c_contiguous:
+        raise ValueError(f"{name} must be a contiguous float64 array of length {n}")
+    return a
+
+
+def _guard_force_params(p: SimParams, routine: str) -> None:
+    # lj_potential_energy.f90:77-81
+    if p.n <= 0:
+        raise ValueError(f"{routine}(): params%n must be > 0.")
+    if p.box_length <= 0.0:
+        raise ValueError(f"{routine}(): params%box_length must be > 0.")
+    if p.volume <= 0.0:
+        raise ValueError(f"{routine}(): params%volume must be > 0.")
+    if p.rc <= 0.0:
+        raise ValueError(f"{routine}(): params%rc must be > 0.")
+    if p.rc_square <= 0.0:
+        raise ValueError(f"{routine}(): params%rc_square must be > 0.")
+
+
+def compute_lj_potential_energy(params: SimParams, state: SimState):
+    """-> (epot, d_epot, dd_epot); overwrites state.ax/ay/az."""
+    _guard_force_params(params, "compute_lj_potential_energy")
+    if not state.allocated():
+        raise ValueError("compute_lj_potential_energy(): state arrays are not allocated.")
+    n = params.n
+    arrs = [_check_array(getattr(state, k), n, k) for k in ("rx", "ry", "rz", "ax", "ay", "az")]
+    e, d, dd = C.c_double(), C.c_double(), C.c_double()
+    lib = _lib.load()
+    _lib.check(lib.ljmd_compute_lj_potential_energy(
+        n, params.box_length, params.rc, *[_ptr(a) for a in arrs],
+        C.byref(e), C.byref(d), C.byref(dd)))
+    return e.value, d.value, dd.value
+
+
+def verlet_step(params: SimParams, state: SimState):
+    """-> (epot, ekin, d_epot, dd_epot); updates all nine state arrays in place."""
+    if params.n <= 0:
+        raise ValueError("verlet_step(): params%n must be > 0.")
+    if not state.allocated():
+        raise ValueError("verlet_step(): state arrays are not allocated.")
+    n = params.n
+    arrs = [_check_array(getattr(state, k), n, k) for k in SimState.FIELDS]
+    out = [C.c_double() for _ in range(4)]
+    lib = _lib.load()
+    _lib.check(lib.ljmd_verlet_step(n, params.box_length, params.dt, params.rc,
+                                    *[_ptr(a) for a in arrs], *[C.byref(o) for o in out]))
+    return tuple(o.value for o in out)
+
+
+def minimum_image(dx: float, box_length: float, inv_box_length: float) -> float:
+    """geometry_pbc.f90:80-88 (dnint = round half away from zero); host helper."""
+    t = dx * inv_box_length
+    n = np.copysign(np.floor(np.abs(t) + 0.5), t)
+    return dx - box_length * n
+
+
+class Engine:
+    """HBM-resident simulation on one GPU (or one shard of a multi-GPU run)."""
+
+    def __init__(self, params: SimParams, device: int = 0, rank: int = 0, n_ranks: int = 1,
+                 precision_mode: int = _lib.PRECISION_FP64):
+        self._lib = _lib.load()
+        self.params = params
+        self.rank, self.n_ranks = rank, n_ranks
+        h = C.c_void_p()
+        _lib.check(self._lib.ljmd_create(C.byref(h), params.n, params.box_length, params.dt, params.rc,
+                                         precision_mode, device, rank, n_ranks))
+        self._h = h
+        self.shard = params.n // n_ranks
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ljmd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, status: int) -> None:
+        _lib.check(status, self._h)
+
+    # -- state transfer ----------------------------------------------------
+    def set_state(self, rx, ry, rz, vx, vy, vz) -> None:
+        n = self.params.n
+        arrs = [_check_array(np.ascontiguousarray(a, dtype=np.float64), n, "state array")
+                for a in (rx, ry, rz, vx, vy, vz)]
+        self._ck(self._lib.ljmd_set_state(self._h, *[_ptr(a) for a in arrs]))
+
+    def set_accel(self, ax, ay, az) -> None:
+        n = self.params.n
+        arrs = [_check_array(np.ascontiguousarray(a, dtype=np.float64), n, "accel array") for a in (ax, ay, az)]
+        self._ck(self._lib.ljmd_set_accel(self._h, *[_ptr(a) for a in arrs]))
+
+    def set_unwrapped(self, ux, uy, uz) -> None:
+        n = self.params.n
+        arrs = [_check_array(np.ascontiguousarray(a, dtype=np.float64), n, "unwrapped array") for a in (ux, uy, uz)]
+        self._ck(self._lib.ljmd_set_unwrapped(self._h, *[_ptr(a) for a in arrs]))
+
+    def get_state(self, which=("r", "ru", "v", "a")) -> dict:
+        """-> {'r': (x,y,z), 'ru': ..., 'v': ..., 'a': ...} of the owned shard."""
+        S = self.shard
+        out, ptrs = {}, []
+        for key in ("r", "ru", "v", "a"):
+            if key in which:
+                arrs = tuple(np.empty(S, dtype=np.float64) for _ in range(3))
+                out[key] = arrs
+                ptrs += [_ptr(a) for a in arrs]
+            else:
+                ptrs += [None, None, None]
+        self._ck(self._lib.ljmd_get_state(self._h, *ptrs))
+        return out
+
+    # -- hot path ----------------------------------------------------------
+    def compute_forces(self):
+        e, d, dd = C.c_double(), C.c_double(), C.c_double()
+        self._ck(self._lib.ljmd_compute_forces(self._h, C.byref(e), C.byref(d), C.byref(dd)))
+        return e.value, d.value, dd.value
+
+    def verlet_steps(self, nsteps: int):
+        """-> (epot[nsteps], ekin[nsteps], d_epot[nsteps], dd_epot[nsteps])"""
+        outs = [np.empty(nsteps, dtype=np.float64) for _ in range(4)]
+        self._ck(self._lib.ljmd_verlet_steps(self._h, nsteps, *[_ptr(o) for o in outs]))
+        return tuple(outs)
+
+    def kinetic_energy(self) -> float:
+        k = C.c_double()
+        self._ck(self._lib.ljmd_kinetic_energy(self._h, C.byref(k)))
+        return k.value
+
+    # -- split phase (multi-GPU) ---------------------------------------------
+    def shard_range(self):
+        i0, i1 = C.c_int32(), C.c_int32()
+        self._ck(self._lib.ljmd_shard_range(self._h, C.byref(i0), C.byref(i1)))
+        return i0.value, i1.value
+
+    def exchange_buffer(self):
+        """-> (device address, total doubles, own offset, own count)"""
+        tot, off, cnt = C.c_int64(), C.c_int64(), C.c_int64()
+        p = self._lib.ljmd_exchange_buffer(self._h, C.byref(tot), C.byref(off), C.byref(cnt))
+        return p, tot.value, off.value, cnt.value
+
+    def device_ptr(self, which: int, axis: int) -> int:
+        return self._lib.ljmd_device_ptr(self._h, which, axis)
+
+    def stream(self) -> int:
+        return self._lib.ljmd_stream(self._h)
+
+    def step_begin(self) -> None:
+        self._ck(self._lib.ljmd_step_begin(self._h))
+
+    def step_finish(self) -> None:
+        self._ck(self._lib.ljmd_step_finish(self._h))
+
+    def forces_partial(self) -> None:
+        self._ck(self._lib.ljmd_forces_partial(self._h))
+
+    def read_partials(self, nsteps: int) -> np.ndarray:
+        out = np.empty((nsteps, _lib.PARTIAL_STRIDE), dtype=np.float64)
+        self._ck(self._lib.ljmd_read_partials(self._h, nsteps, _ptr(out)))
+        return out
+
+    def combine_scalars(self, partials_by_rank: np.ndarray):
+        """partials_by_rank: [n_ranks, PARTIAL_STRIDE] of ONE step -> (epot, ekin, d_epot, dd_epot)"""
+        p = np.ascontiguousarray(partials_by_rank, dtype=np.float64)
+        outs = [C.c_double() for _ in range(4)]
+        self._ck(self._lib.ljmd_combine_scalars(self._h, _ptr(p), p.shape[0], *[C.byref(o) for o in outs]))
+        return tuple(o.value for o in outs)
+
+    # -- measurement -----------------------------------------------------------
+    def profile_enable(self, on: bool = True) -> None:
+        self._ck(self._lib.ljmd_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        f, g, c = C.c_double(), C.c_double(), C.c_int32()
+        self._ck(self._lib.ljmd_profile_read(self._h, C.byref(f), C.byref(g), C.byref(c)))
+        return f.value, g.value, c.value
+
+
+def observables(params: SimParams, epot: float, ekin: float, d_epot: float):
+    """etot, T, P of one sample: md_simulation_program.f90:355,366 + md_means.f90:215-228.
+    Note T uses 3N (not 3N-3) in the time series."""
+    npd = float(params.n)
+    rho = npd / params.volume
+    virial = -d_epot
+    etot = epot + ekin
+    temp = 2.0 * ekin / (3.0 * npd)
+    press = rho * temp + virial / (3.0 * params.volume)
+    return etot, temp, press

@@ -1,0 +1,89 @@
+"""Production-run loop around the resident engine: the host-side mirror of
+`program md_simulation` (scripts/md_simulation_program.f90:208-391) restricted to what
+touches the hot path -- parameter + rv_init input, t=0 forces, the MD loop, the sampling
+condition, instantaneous_energies.dat and rva.dat output.  The statistics modules
+(md_means accumulators, md_correlations, thermodynamic_coefs) are out of scope.
+
+Between two sampling steps the state never leaves HBM: the loop advances
+`steps until next sample` with one ljmd_verlet_steps call and reads r/ru/v/a back only
+when a snapshot is due.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+from . import io_formats
+from .physics import Engine, observables
+from .read_input_files import RunControl, read_simulation_parameters
+
+
+@dataclass
+class RunResult:
+    n_samples: int = 0
+    time: list = field(default_factory=list)
+    epot: list = field(default_factory=list)
+    ekin: list = field(default_factory=list)
+    etot: list = field(default_factory=list)
+    temp: list = field(default_factory=list)
+    press: list = field(default_factory=list)
+    steps_per_second: float = 0.0
+
+
+def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunResult:
+    """Runs `root_dir/inputs/input_simulation_parameters.txt` from `root_dir/outputs/rv_init.dat`
+    and writes root_dir/outputs/one_run/{instantaneous_energies.dat, rva.dat}."""
+    import time as _time
+
+    root = Path(root_dir)
+    ctl: RunControl = read_simulation_parameters(root / "inputs" / "input_simulation_parameters.txt")
+    p = ctl.params
+    r, v = io_formats.read_rv_init(root / "outputs" / "rv_init.dat", p.n)
+    out_dir = root / "outputs" / "one_run"
+    if not out_dir.is_dir():
+        # md_simulation_program.f90:250 stops when the directory is missing
+        raise ValueError("md_simulation: cannot open outputs/one_run/rva.dat")
+
+    n_snap = max(0, ctl.total_steps // ctl.output_interval - ctl.warmup_steps // ctl.output_interval)  # :254-255
+    res = RunResult()
+    with Engine(p, device=device) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])        # :221-231 (ru <- r)
+        eng.compute_forces()                                     # :236
+        rva = io_formats.RvaWriter(out_dir / "rva.dat", p.n, p.box_length, p.dt, ctl.output_interval,
+                                   n_snap) if write_rva else None
+        f_en = open(out_dir / "instantaneous_energies.dat", "w")
+        f_en.write(io_formats.ENERGIES_HEADER + "\n")
+        t = 0.0
+        step = 0
+        t0 = _time.perf_counter()
+        while step < ctl.total_steps:
+            # next sampling step strictly after `step` (condition of :361)
+            nxt = (step // ctl.output_interval + 1) * ctl.output_interval
+            while nxt <= ctl.warmup_steps:
+                nxt += ctl.output_interval
+            nxt = min(nxt, ctl.total_steps)
+            count = nxt - step
+            epot, ekin, d_epot, _dd = eng.verlet_steps(count)
+            for _ in range(count):
+                t = t + p.dt                                      # :356 accumulated, not step*dt
+            step = nxt
+            if step > ctl.warmup_steps and step % ctl.output_interval == 0:
+                e, k, d = epot[-1], ekin[-1], d_epot[-1]
+                etot, temp, press = observables(p, e, k, d)
+                f_en.write(io_formats.energies_row(t, e, k, etot, temp, press) + "\n")   # :374
+                res.n_samples += 1
+                for lst, val in ((res.time, t), (res.epot, e), (res.ekin, k), (res.etot, etot),
+                                 (res.temp, temp), (res.press, press)):
+                    lst.append(val)
+                if rva is not None:
+                    st = eng.get_state()
+                    rva.write_snapshot(st["r"], st["ru"], st["v"], st["a"])           # :384-387
+        res.steps_per_second = ctl.total_steps / max(_time.perf_counter() - t0, 1e-12)
+        f_en.close()
+        if rva is not None:
+            rva.close()
+    if res.n_samples <= 0:
+        raise ValueError("md_simulation: no samples were taken (check warmup_steps/output_interval).")  # :396
+    return res
