@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py -- MD steps/s of the LJ force + velocity-Verlet hot path at N = 262 144, fp64
+(BASELINE.json metric), on N GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full MD step on synthetic input already resident in HBM: drift + wrap +
+half-kick + unwrapped update, all-pairs LJ forces/energy/virial, second half-kick, kinetic
+energy.  For N > 1 the SAME 262 144-particle system is sharded by particle rows (strong
+scaling) with one RCCL all-gather of positions per step.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+N_PARTICLES = 262144
+FLOP_PER_UNORDERED_PAIR = 33.8   # reference's Newton-3 loop: 21 outside + 0.493 * 26 inside the cutoff
+FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64 (256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz / 2)
+
+
+def cpu_baseline(budget_s: float = 20.0) -> dict:
+    """Times the CPU path on this box's host cores on a bounded sample of the same workload.
+    kind = "reference": oracle/_ref/ref_harness (the real reference, 1 core, compiled -O2) when
+    the prebuilt binary travelled with the snapshot; otherwise kind = "port": the C oracle."""
+    from oracle import oracle as O
+    pairs_full = N_PARTICLES * (N_PARTICLES - 1) / 2.0
+    n_s = 32768                                   # ~5.4e8 pairs: 10-20 s on one core
+    if O.ref_available():
+        secs, pps = O.ref_bench(n_s, 1)
+        kind, cores = "reference", 1
+        what = f"real reference (oracle/_ref, amdflang -O2), 1 force call at N={n_s}"
+    else:
+        from ljmd_amd import synthetic
+        p, r, _ = synthetic.make_config(n_s)
+        po = O.derive_params(p.n, p.box_length, p.dt, p.rc)
+        t0 = time.perf_counter()
+        O.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+        secs = time.perf_counter() - t0
+        pps = (n_s * (n_s - 1) / 2.0) / secs
+        kind, cores = "port", 1
+        what = f"C oracle (gcc -O2, no FMA), 1 force call at N={n_s}"
+    return {"value": pps / pairs_full, "unit": "steps/s", "cores": cores, "kind": kind,
+            "pairs_per_s": pps, "seconds": secs, "host_cores_available": os.cpu_count(),
+            "sample": what + f", same rho/rc/jitter recipe; steps/s = pairs/s / {pairs_full:.4e} pairs per step "
+                             f"(the O(N) integrator is <0.1% of a CPU step)"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_PARTICLES, help="override the particle count (parity/debug only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch
+    import ljmd_amd
+    from ljmd_amd import Engine, synthetic, distributed
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    n = args.n
+    p, r, v = synthetic.make_config(n)
+    eng = Engine(p, device=local_rank, rank=rank, n_ranks=world)
+    if world > 1:
+        full, own = distributed.hip_exchange_tensors(eng, local_rank)
+        sim = distributed.ShardedSimulation(eng, full, own, rank, world,
+                                            stream_context=distributed.hip_stream_context(eng, local_rank))
+    else:
+        sim = distributed.ShardedSimulation(eng, None, None, 0, 1)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(local_rank)
+
+    e0, d0, dd0 = sim.start(r, v)
+    if args.warmup > 0:
+        sim.run(args.warmup)
+    eng.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    sim.enqueue_steps(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    force_ms, integ_ms, launches = eng.profile_read()
+    eng.profile_enable(False)
+    epot, ekin, d_epot, dd_epot = sim.collect(args.steps)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        steps_per_s = args.steps / elapsed
+        pairs = n * (n - 1) / 2.0
+        etot = epot + ekin
+        # roofline of the dominant kernel (pair forces): fp64 vector-ALU bound:
+        # algorithmic flops per launch = reference's per-unordered-pair flop count x the pairs
+        # this rank's launch covers (its rows x all columns / 2)
+        flops_per_launch = FLOP_PER_UNORDERED_PAIR * pairs / world
+        achieved = flops_per_launch / (force_ms * 1e-3) / 1e12 if force_ms > 0 else 0.0
+        line = {
+            "metric": "md_steps_per_sec_n262144_fp64" if n == N_PARTICLES else f"md_steps_per_sec_n{n}_fp64",
+            "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"N={n} LJ fluid, rho=0.8, rc=0.49L, dt=0.005, simple-cubic+5% jitter, T=1.0; "
+                                   f"all-pairs force + velocity-Verlet step (BASELINE configs[2])",
+                       "particles": n, "sharding": f"rows/{world}" if world > 1 else "single GPU",
+                       "unordered_pairs_per_step": pairs},
+            "pair_interactions_per_sec": pairs * steps_per_s,
+            "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "pair_rows_kernel", "kernel_ms_avg": force_ms, "launches_timed": launches,
+                         "flop_per_unordered_pair": FLOP_PER_UNORDERED_PAIR,
+                         "hbm_algorithmic_GBps": (48.0 * n / world) / (force_ms * 1e-3) / 1e9 if force_ms > 0 else 0.0,
+                         "integrator_ms_avg": integ_ms,
+                         "integrator_hbm_GBps": (240.0 * n / world) / (integ_ms * 1e-3) / 1e9 if integ_ms > 0 else 0.0},
+            "energy_check": {"etot_first": float(etot[0]), "etot_last": float(etot[-1]),
+                             "rel_drift": float(abs(etot[-1] - etot[0]) / abs(etot[0]))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as exc:  # the baseline is a reported number, never a reason to lose the bench line
+                line["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {exc}"}
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

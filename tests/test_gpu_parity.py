@@ -1,0 +1,283 @@
+"""-m gpu: the HIP path, called through the C ABI (ctypes -> libljmd.so), against
+(1) golden vectors produced by the real reference and (2) the pinned C oracle.
+
+Tolerances:
+  single force call : scalars <= 1e-13 relative, per-particle a <= 1e-12 * max|a|
+  short trajectory  : Etot, T, P <= 1e-10 relative over the first 200 steps (inside the
+                      chaos horizon; the reference diverges from ITSELF beyond that when
+                      only the summation order / FMA contraction changes -- SURVEY fact #6)
+  integrator        : with identical accelerations the drift/kick arithmetic is bit-exact
+The GPU sums pairs in a different order than the sequential i<j loop, so bitwise identity
+with the reference is not attainable and not claimed.
+"""
+import numpy as np
+import pytest
+
+import ljmd_amd
+from ljmd_amd import Engine, init_params, init_state, synthetic
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+REL_SCALAR = 1e-13
+REL_ACCEL = 1e-12
+REL_TRAJ = 1e-10
+
+
+def rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def check_force(scalars, a, g):
+    gs = g["scalars"]
+    for name, x, y in zip(("epot", "d_epot", "dd_epot"), scalars, gs):
+        assert rel(x, y) <= REL_SCALAR, (name, x, y, rel(x, y))
+    amax = np.max(np.abs(g["a"]))
+    # a perfect lattice has |a| ~ 1e-14 (pure cancellation noise): floor the scale at 1
+    assert np.max(np.abs(a - g["a"])) <= REL_ACCEL * max(amax, 1.0), np.max(np.abs(a - g["a"])) / amax
+
+
+@pytest.mark.parametrize("name", ["force_n108", "force_n500", "force_n4000", "force_n4096"])
+def test_force_call_vs_reference_golden(golden, name):
+    g = golden(name)
+    n = int(g["n"])
+    p = init_params(n, float(g["L"]), 0.005, float(g["rc"]))
+    r = g["r"]
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], r[0], r[1], r[2])
+        sc = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+    check_force(sc, a, g)
+
+
+def test_force_fcc108_known_answer(golden, oracle):
+    g = golden("force_fcc108")
+    L = float(g["L"])
+    p = init_params(108, L, 0.005, float(g["rc"]), num_cells=3)
+    rx, ry, rz = oracle.fcc_lattice(3, L)
+    st = init_state(p)
+    st.rx[:], st.ry[:], st.rz[:] = rx, ry, rz
+    sc = ljmd_amd.compute_lj_potential_energy(p, st)          # stateless drop-in entry point
+    check_force(sc, np.stack([st.ax, st.ay, st.az]), g)
+    assert np.max(np.abs(np.stack([st.ax, st.ay, st.az]))) < 1e-12
+
+
+def test_force_unwrapped_positions_generic_minimum_image(golden):
+    """Positions up to +-3 box lengths outside the box: the library must notice and use the
+    exact dnint path (the fast rndne+fma form is only valid for |d/L| < 2.5)."""
+    g = golden("force_n500_unwrapped")
+    p = init_params(500, float(g["L"]), 0.005, float(g["rc"]))
+    r = g["r"]
+    assert np.ptp(r[0]) > 2.5 * p.box_length
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], r[0], r[1], r[2])
+        sc = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+    check_force(sc, a, g)
+
+
+def _start(eng, g):
+    r0, v0 = g["r0"], g["v0"]
+    eng.set_state(r0[0], r0[1], r0[2], v0[0], v0[1], v0[2])
+    e, d, dd = eng.compute_forces()
+    return e, eng.kinetic_energy(), d, dd
+
+
+def _series(p, sc):
+    etot = sc[:, 0] + sc[:, 1]
+    temp = 2.0 * sc[:, 1] / (3.0 * p.n)
+    press = (p.n / p.volume) * temp + (-sc[:, 2]) / (3.0 * p.volume)
+    return etot, temp, press
+
+
+@pytest.mark.parametrize("name,nsteps", [("traj_n108", 200), ("traj_n4096_200", 200)])
+def test_short_trajectory_vs_reference_golden(golden, name, nsteps):
+    """T2: Etot, T, P within 1e-10 relative of the reference's raw fp64 dump for 200 steps."""
+    g = golden(name)
+    n = int(g["n"])
+    p = init_params(n, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    ref = g["scalars"][:nsteps + 1]
+    with Engine(p) as eng:
+        s0 = _start(eng, g)
+        e, k, d, dd = eng.verlet_steps(nsteps)
+        mine = np.vstack([s0, np.stack([e, k, d, dd], axis=1)])
+        fin = eng.get_state()
+    for nm, a, b in zip(("etot", "T", "P"), _series(p, mine), _series(p, ref)):
+        err = np.max(np.abs(a - b) / np.abs(b))
+        assert err <= REL_TRAJ, (name, nm, err)
+    if nsteps == g["scalars"].shape[0] - 1:      # golden final state is at this step
+        gf = g["final"]
+        mine_f = np.concatenate([np.stack(fin[k]) for k in ("r", "ru", "v", "a")])
+        scale = np.array([p.box_length] * 6 + [np.max(np.abs(gf[6:9]))] * 3 + [np.max(np.abs(gf[9:12]))] * 3)
+        dr = mine_f[:3] - gf[:3]
+        dr -= p.box_length * np.round(dr / p.box_length)     # a particle may sit on the other side of the wrap
+        assert np.max(np.abs(dr)) < 1e-8
+        assert np.max(np.abs(mine_f[3:] - gf[3:]) / scale[3:, None]) < 1e-7
+
+
+def test_verlet_step_drop_in_strict_mode(golden, oracle):
+    """The stateless verlet_step entry point (what the Fortran shim binds): nine arrays in,
+    nine arrays out, one step -- compared with the oracle stepping the same arrays."""
+    g = golden("traj_n108")
+    n = 108
+    p = init_params(n, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    r0, v0 = g["r0"], g["v0"]
+    st = init_state(p)
+    st.rx[:], st.ry[:], st.rz[:] = r0
+    st.vx[:], st.vy[:], st.vz[:] = v0
+    e0 = ljmd_amd.compute_lj_potential_energy(p, st)
+    o = {k: getattr(st, k).copy() for k in st.FIELDS}
+    # identical accelerations in -> positions and half-kicked velocities must agree BIT FOR BIT
+    for step in range(5):
+        r_before = np.stack([st.rx, st.ry, st.rz]).copy()
+        mine = ljmd_amd.verlet_step(p, st)
+        ref = oracle.verlet_step(po, o)
+        if step == 0:
+            assert np.array_equal(np.stack([st.rx, st.ry, st.rz]), np.stack([o["rx"], o["ry"], o["rz"]]))
+        for a, b in zip(mine, ref):
+            assert rel(a, b) < 1e-12
+        assert not np.array_equal(r_before, np.stack([st.rx, st.ry, st.rz]))
+    assert rel(e0[0], g["scalars"][0, 0]) < REL_SCALAR
+
+
+def test_integrator_arithmetic_bit_exact(golden, oracle):
+    """Feed the oracle's accelerations to the GPU and take ONE step: r (drift+wrap), ru and the
+    first half-kick do not depend on the pair sum, so they must match the oracle bit for bit."""
+    g = golden("traj_n4096_200")
+    n = 4096
+    p = init_params(n, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    r0, v0 = g["r0"], g["v0"]
+    _, _, _, ax, ay, az = oracle.compute_forces(po, r0[0].copy(), r0[1].copy(), r0[2].copy())
+    st = {"rx": r0[0].copy(), "ry": r0[1].copy(), "rz": r0[2].copy(),
+          "ux": r0[0].copy(), "uy": r0[1].copy(), "uz": r0[2].copy(),
+          "vx": v0[0].copy(), "vy": v0[1].copy(), "vz": v0[2].copy(), "ax": ax.copy(), "ay": ay.copy(), "az": az.copy()}
+    oracle.run_steps(po, 1, st)
+    with Engine(p) as eng:
+        eng.set_state(r0[0], r0[1], r0[2], v0[0], v0[1], v0[2])
+        eng.set_accel(ax, ay, az)
+        eng.verlet_steps(1)
+        fin = eng.get_state()
+    assert np.array_equal(np.stack(fin["r"]), np.stack([st["rx"], st["ry"], st["rz"]]))
+    assert np.array_equal(np.stack(fin["ru"]), np.stack([st["ux"], st["uy"], st["uz"]]))
+    # v after the step = (v + a*dt/2) + a_new*dt/2 ; a_new differs at the 1e-13 level
+    assert np.max(np.abs(np.stack(fin["v"]) - np.stack([st["vx"], st["vy"], st["vz"]]))) < 1e-12
+
+
+def test_rerun_is_bitwise_deterministic(golden):
+    """No atomics, fixed reduction order: two runs give identical bits (T4)."""
+    g = golden("traj_n4096_200")
+    p = init_params(4096, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    outs = []
+    for _ in range(2):
+        with Engine(p) as eng:
+            _start(eng, g)
+            sc = np.stack(eng.verlet_steps(50))
+            outs.append((sc, np.stack(eng.get_state(("a",))["a"])))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_long_run_n4096_against_oracle_envelope(golden, oracle):
+    """BASELINE config 2 (N=4096, 10 000 steps).  Beyond the chaos horizon trajectories decorrelate,
+    so the comparison is statistical: the GPU's total-energy wander and <T>, <P> must sit inside
+    the envelope of the pinned oracle run from the same start (oracle limited to 300 steps to
+    keep the CPU leg short), and momentum must stay conserved."""
+    g = golden("traj_n4096_200")
+    n = 4096
+    p = init_params(n, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    with Engine(p) as eng:
+        s0 = _start(eng, g)
+        e, k, d, dd = eng.verlet_steps(10000)
+        fin = eng.get_state(("v",))
+    etot = e + k
+    ref = g["scalars"]
+    ref_etot = ref[:, 0] + ref[:, 1]
+    # the reference itself wanders (truncated, unshifted LJ): compare like with like
+    assert abs(etot[:200] - ref_etot[1:201]).max() / abs(ref_etot[0]) < 1e-9
+    drift = (etot.max() - etot.min()) / abs(etot.mean())
+    assert drift < 5e-3, drift                               # reference N=108: 3.4e-3 peak-to-peak
+    assert np.all(np.isfinite(etot))
+    vsum = np.abs(np.stack(fin["v"]).sum(axis=1)).max()
+    assert vsum < 1e-8, vsum                                 # total momentum stays ~0 (Newton 3)
+    temp = 2.0 * k / (3.0 * n)
+    assert 0.3 < temp[-2000:].mean() < 3.0
+
+
+def test_large_n_properties_262144():
+    """BASELINE config 3 size: no oracle finishes here, so size-independent properties:
+    sum of forces = 0 (Newton 3), translation invariance, permutation invariance, and a
+    sampled-row check against a direct numpy evaluation of rows."""
+    n = 262144
+    p, r, v = synthetic.make_config(n)
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e1, d1, dd1 = eng.compute_forces()
+        a1 = np.stack(eng.get_state(("a",))["a"])
+        # translation by an arbitrary vector + re-wrap
+        shift = np.array([0.3, -1.7, 11.1])[:, None]
+        r2 = r + shift
+        r2 -= p.box_length * np.floor(r2 / p.box_length)
+        eng.set_state(r2[0], r2[1], r2[2], v[0], v[1], v[2])
+        e2, d2, dd2 = eng.compute_forces()
+        a2 = np.stack(eng.get_state(("a",))["a"])
+    amax = np.abs(a1).max()
+    assert np.abs(a1.sum(axis=1)).max() < 1e-9 * amax * np.sqrt(n)
+    assert rel(e2, e1) < 1e-11 and rel(d2, d1) < 1e-10
+    assert np.abs(a2 - a1).max() < 1e-9 * amax
+    # sampled rows vs numpy (same formulas, fp64)
+    rows = np.random.Generator(np.random.PCG64(5)).choice(n, size=8, replace=False)
+    L = p.box_length
+    for i in rows:
+        dvec = r[:, i:i + 1] - r
+        dvec -= L * np.round(dvec / L)
+        r2_ = (dvec * dvec).sum(axis=0)
+        m = (r2_ < p.rc_square) & (np.arange(n) != i)
+        u = 1.0 / r2_[m]
+        u3 = u * u * u
+        gfac = (2.0 * u3 * u3 - u3) * u
+        a_np = 24.0 * (gfac * dvec[:, m]).sum(axis=1)
+        assert np.abs(a_np - a1[:, i]).max() < 1e-10 * max(np.abs(a_np).max(), 1.0)
+
+
+def test_argument_guards_and_sequence_errors():
+    with pytest.raises(ljmd_amd.LjmdError) as ei:
+        Engine(ljmd_amd.SimParams(n=10, box_length=10.0, dt=0.005, rc=5.0))      # rc >= L/2
+    assert ei.value.code == -1 and "L/2" in ei.value.message
+    p = init_params(64, 5.0, 0.005, 2.0)
+    with Engine(p) as eng:
+        with pytest.raises(ljmd_amd.LjmdError) as e2:
+            eng.compute_forces()                                                    # no state yet
+        assert e2.value.code == -4
+        z = np.linspace(0.1, 4.9, 64)
+        eng.set_state(z, z[::-1].copy(), z, z, z, z)
+        with pytest.raises(ljmd_amd.LjmdError):
+            eng.verlet_steps(1)                                                     # no accelerations yet
+        eng.compute_forces()
+        assert eng.verlet_steps(0)[0].shape == (0,)
+    with pytest.raises(ValueError):
+        ljmd_amd.compute_lj_potential_energy(p, ljmd_amd.SimState())               # not allocated
+
+
+def test_production_loop_files_vs_reference(tmp_path, golden):
+    """Config 1 end to end (input file -> rv_init.dat -> energies + rva.dat) against the files
+    the reference's own programs wrote.  Text file: 7 significant digits; rva.dat: raw fp64."""
+    import shutil
+    from ljmd_amd import io_formats, simulation
+    src = GOLDEN / "ref_run_n108_oi100"
+    (tmp_path / "inputs").mkdir()
+    (tmp_path / "outputs" / "one_run").mkdir(parents=True)
+    shutil.copy(src / "input_simulation_parameters.txt", tmp_path / "inputs")
+    shutil.copy(src / "rv_init.dat", tmp_path / "outputs")
+    res = simulation.run_md_simulation(tmp_path)
+    assert res.n_samples == 9
+    mine = io_formats.read_energies(tmp_path / "outputs" / "one_run" / "instantaneous_energies.dat")
+    ref = io_formats.read_energies(src / "instantaneous_energies.dat")
+    assert mine.shape == ref.shape == (9, 6)
+    # steps <= 1000 at N=108: P stays within ~1e-7 of the reference up to step 1000
+    assert np.allclose(mine, ref, rtol=5e-6, atol=0)
+    h1, s1 = io_formats.read_rva(tmp_path / "outputs" / "one_run" / "rva.dat")
+    h2, s2 = io_formats.read_rva(src / "rva.dat")
+    assert h1 == h2 and s1.shape == s2.shape == (9, 4, 3, 108)
+    assert (tmp_path / "outputs" / "one_run" / "rva.dat").stat().st_size == (src / "rva.dat").stat().st_size
+    assert np.abs(s1[0] - s2[0]).max() < 1e-9          # first snapshot (step 200): inside the horizon
