@@ -51,6 +51,7 @@ typedef enum ljmd_status {
 
 /* Which state array: argument of ljmd_device_ptr / selectors of get_state. */
 enum { LJMD_R = 0, LJMD_RU = 1, LJMD_V = 2, LJMD_A = 3 };
+#define LJMD_PARTIAL_STRIDE 8
 
 /* ---- library-level ------------------------------------------------------ */
 
@@ -146,14 +147,15 @@ void ljmd_stateless_reset(void);
 int ljmd_shard_range(const ljmd_t *h, int32_t *i0, int32_t *i1);
 /*
  * Device address of the exchange buffer holding ALL n positions in shard-blocked
- * SoA order: block g (g = 0..n_ranks-1) is x[S] y[S] z[S] of rank g's particles,
- * S = n/n_ranks.  Rank g's own block is at offset g*3*S doubles, so one in-place
- * RCCL all-gather of 3*S doubles per rank refreshes it.  (n_ranks = 1: plain SoA.)
+ * SoA order: block g (g = 0..n_ranks-1) is x[P] y[P] z[P] of rank g's particles in
+ * rank g's current (spatially sorted) slot order, P = n/n_ranks rounded up to a
+ * multiple of 256, padding slots = NaN.  Rank g's own block is at offset g*3*P
+ * doubles, so one in-place RCCL all-gather of 3*P doubles per rank refreshes it.
  */
 void *ljmd_exchange_buffer(ljmd_t *h, int64_t *n_doubles_total, int64_t *own_offset_doubles,
                            int64_t *own_count_doubles);
-/* Device address of one resident state array (LJMD_R..LJMD_A, axis 0..2), length
- * = shard size; for zero-copy views (e.g. torch via __cuda_array_interface__). */
+/* Device address of one resident state array (LJMD_R..LJMD_A, axis 0..2), P slots in
+ * the current device slot order; for zero-copy views (e.g. torch via __cuda_array_interface__). */
 void *ljmd_device_ptr(ljmd_t *h, int32_t which, int32_t axis);
 /* The HIP stream (hipStream_t) all of this handle's kernels are launched on. */
 void *ljmd_stream(ljmd_t *h);
@@ -166,9 +168,9 @@ int ljmd_step_finish(ljmd_t *h);
 /* Pair forces only (t = 0 evaluation) on the exchange buffer contents. */
 int ljmd_forces_partial(ljmd_t *h);
 /*
- * Copies out the raw per-rank partial sums of the last `nsteps` finished phases:
- * partial[4*k + {0,1,2,3}] = { sum u^-12 , sum u^-6 , sum |v|^2 contributions (x,y,z
- * added) , 0 } -- see ljmd_combine_scalars.  Resets the ring.
+ * Copies out the raw per-rank partial records of the last `nsteps` finished phases,
+ * LJMD_PARTIAL_STRIDE (8) doubles each: { sum r^-12, sum r^-6 over this rank's ordered
+ * pairs, sum vx^2, sum vy^2, sum vz^2 over its particles, 0, 0, 0 }.  Resets the ring.
  */
 int ljmd_read_partials(ljmd_t *h, int32_t nsteps, double *partial);
 /* Host-side, deterministic: combines the n_ranks partial records of ONE step (rank
@@ -178,11 +180,16 @@ int ljmd_combine_scalars(const ljmd_t *h, const double *partials_by_rank, int32_
 
 /* ---- measurement --------------------------------------------------------- */
 
-/* Average device time in milliseconds of the pair-force kernel over the launches
- * since the last call (HIP events on the handle's own stream); *launches = count.
- * Timing is armed by ljmd_profile_enable(h, 1). */
+/*
+ * Live HIP-event timing on the handle's own stream.  After ljmd_profile_enable(h, 1)
+ * every step / force evaluation records events around its kernels; ljmd_profile_read
+ * waits for the stream and returns averages per launch in milliseconds:
+ *   ms_avg[0] pair-force kernel          ms_avg[1] geometry pre-pass (tile boxes + mask)
+ *   ms_avg[2] drift/kick kernel (+ re-sort)   ms_avg[3] slab reduce + kick + finalize
+ * *launches = number of launches averaged; the counters are reset.
+ */
 int ljmd_profile_enable(ljmd_t *h, int32_t on);
-int ljmd_profile_read(ljmd_t *h, double *force_ms_avg, double *integrate_ms_avg, int32_t *launches);
+int ljmd_profile_read(ljmd_t *h, double *ms_avg /* [4] */, int32_t *launches);
 
 #ifdef __cplusplus
 }

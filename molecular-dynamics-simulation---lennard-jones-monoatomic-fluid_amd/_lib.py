@@ -68,7 +68,7 @@ PROTOTYPES = {
     "ljmd_read_partials": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "ljmd_combine_scalars": (C.c_int, [C.c_void_p, c_double_p, C.c_int32] + [c_double_p] * 4),
     "ljmd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
-    "ljmd_profile_read": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p]),
+    "ljmd_profile_read": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
 }
 
 _lib = None

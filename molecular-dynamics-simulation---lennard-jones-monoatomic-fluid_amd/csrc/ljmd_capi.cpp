@@ -1,8 +1,8 @@
 // ljmd_capi.cpp -- host side of libljmd.so: the C ABI declared in include/ljmd.h.
 //
 // Owns the HBM-resident simulation state and sequences the gfx950 kernels of
-// ljmd_kernels.hip on one HIP stream.  There is no CPU compute path in this
-// library: without a HIP device every compute entry point returns
+// ljmd_kernels.hip / ljmd_sort.hip on one HIP stream.  There is no CPU compute path in
+// this library: without a HIP device every compute entry point returns
 // LJMD_ERR_NO_DEVICE.
 #include "ljmd.h"
 
@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -26,48 +27,75 @@ namespace {
 thread_local std::string g_last_error = "";
 
 constexpr unsigned kRingCap = 4096;     // per-step partial records kept on the device
-constexpr int kTargetWorkgroups = 2048; // >> 256 CUs (8 per CU) for the pair kernel
+constexpr int kTargetWorkgroups = 2048; // >> 256 CUs (8 per CU) for the pair kernels
 constexpr int kMaxProfiledLaunches = 4096;
+constexpr int kEventsPerLaunch = 5;
 
 // md_types.f90:22
 constexpr double kPi = 3.1415926535897932384626433832795;
 
-struct EventQuad {
-    hipEvent_t e[4];
+struct EventSet {
+    hipEvent_t e[kEventsPerLaunch];  // 0: before K1, 1: before geometry, 2: before pair, 3: after pair, 4: end
 };
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = std::getenv(name);
+    return (v && *v) ? std::atoi(v) : dflt;
+}
 
 }  // namespace
 
 struct ljmd {
     // ---- parameters (type(sim_params), md_types.f90:27-50) ----
-    int n = 0, shard = 0, rank = 0, n_ranks = 1, device = 0, mode = 0;
+    int n = 0, S = 0, P = 0, rank = 0, G = 1, device = 0, mode = 0;
+    int TB = 0, T = 0, W = 0;
     double L = 0, invL = 0, volume = 0, rc = 0, rc2 = 0, dt = 0, dt_half = 0, dt_sq_half = 0;
     double tail_e = 0, tail_d = 0, tail_dd = 0;
-    bool rc_allows_fast_mic = false;  // rc <= (1 - 1e-9) * L/2
+    bool rc_allows_fast = false;      // rc <= (1 - 1e-9) * L/2
     bool positions_compact = false;   // coordinate spread < 2.4 L (always true after a wrap)
     bool have_state = false, have_accel = false;
+    bool sort_enabled = true;
+    bool force_generic = false;       // LJMD_FORCE_GENERIC=1: always take the exact generic kernel (A/B tests)
+    int resort_every = 10, steps_since_sort = 0, ncell = 1;
 
     hipStream_t stream = nullptr;
-    // ---- HBM-resident state ----
-    double *d_pos = nullptr;      // [n_ranks][3][shard]  exchange buffer (all positions)
-    double *d_ru = nullptr;       // [3][shard]
-    double *d_v = nullptr;        // [3][shard]
-    double *d_a = nullptr;        // [3][shard]
-    double *d_slab = nullptr;     // [nslab][3][shard]
-    double *d_wg_part = nullptr;  // [n_wg][2]
+    // ---- HBM-resident state (layout: ljmd_internal.h) ----
+    double *d_pos = nullptr;      // [G][3][P] exchange buffer (all positions)
+    double *d_ru = nullptr, *d_v = nullptr, *d_a = nullptr;   // [3][P]
+    double *d_slab = nullptr;     // [nslab_max][3][P]
+    double *d_wg_part = nullptr;  // [n_wg_max][2]
     double *d_ke_part = nullptr;  // [n_ke][3]
     double *d_ring = nullptr;     // [kRingCap][kPartialStride]
     unsigned *d_ring_pos = nullptr;
+    double *d_bbox = nullptr;     // [T][kBoxStride]
+    uint64_t *d_mask = nullptr;   // [TB][W]
+    // sorting scratch
+    unsigned *d_keys = nullptr, *d_keys2 = nullptr;
+    int *d_idx = nullptr, *d_idx2 = nullptr, *d_perm = nullptr, *d_perm2 = nullptr;
+    double *d_tmp3 = nullptr;     // [3][P]
+    void *d_cub = nullptr;
+    size_t cub_bytes = 0;
+
     unsigned ring_consumed = 0;   // host mirror: records already read back
     unsigned ring_issued = 0;     // host mirror: finalize launches issued
-    int nslab = 1, chunk = 0, n_wg = 0, n_ke = 0;
-    dim3 pair_grid;
+    // launch geometry
+    int nslab_g = 1, chunk_g = 0;     // generic kernel: grid (P/256, nslab_g), chunk_g j per slice
+    int nslab_t = 1, chunk_t = 0;     // tile kernel:    grid (TB/4, nslab_t), chunk_t mask words per slice
+    // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
+    bool use_n3 = false;
+    int NG = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
+    double *d_slab_j = nullptr;
+    unsigned char *d_flag_j = nullptr;
+    int n_ke = 0;
 
-    double *h_stage = nullptr;    // pinned, 3*n doubles
+    double *h_stage = nullptr;    // pinned, 3*G*P doubles
     double *h_ring = nullptr;     // pinned, kRingCap records
+    std::vector<int> h_perm;      // slot -> original local index (>= S on padding)
+    bool perm_dirty = false;
 
     bool profiling = false;
-    std::vector<EventQuad> ev_pool;
+    std::vector<EventSet> ev_pool;
     size_t ev_used = 0;
 
     std::string err;
@@ -75,7 +103,7 @@ struct ljmd {
 
 namespace {
 
-int fail(ljmd_t *h, int code, const char *fmt, ...)
+int fail(const ljmd_t *h, int code, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -83,7 +111,7 @@ int fail(ljmd_t *h, int code, const char *fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_last_error = buf;
-    if (h) h->err = buf;
+    if (h) const_cast<ljmd_t *>(h)->err = buf;
     return code;
 }
 
@@ -95,38 +123,92 @@ int fail(ljmd_t *h, int code, const char *fmt, ...)
                         hipGetErrorString(e_), __FILE__, __LINE__);                         \
     } while (0)
 
-double *own_block(ljmd_t *h) { return h->d_pos + (size_t)h->rank * 3 * h->shard; }
+double *own_block(ljmd_t *h) { return h->d_pos + (size_t)h->rank * 3 * h->P; }
 
-PairArgs pair_args(ljmd_t *h)
+bool fast_path_ok(const ljmd_t *h) { return h->rc_allows_fast && h->positions_compact && !h->force_generic; }
+
+PairArgs pair_args(ljmd_t *h, bool fast)
 {
     PairArgs a;
     a.pos = h->d_pos;
     a.slab = h->d_slab;
     a.wg_part = h->d_wg_part;
+    a.mask = h->d_mask;
     a.n = h->n;
-    a.shard = h->shard;
+    a.S = h->S;
+    a.P = h->P;
+    a.G = h->G;
     a.rank = h->rank;
-    a.row0 = h->rank * h->shard;
-    a.rows = h->shard;
-    a.chunk = h->chunk;
+    a.TB = h->TB;
+    a.T = h->T;
+    a.W = h->W;
+    a.chunk = fast ? h->chunk_t : h->chunk_g;
     a.L = h->L;
     a.invL = h->invL;
     a.rc2 = h->rc2;
     return a;
 }
 
-IntegrateArgs integrate_args(ljmd_t *h)
+GeometryArgs geometry_args(ljmd_t *h)
+{
+    GeometryArgs a;
+    a.pos = h->d_pos;
+    a.bbox = h->d_bbox;
+    a.mask = h->d_mask;
+    a.P = h->P;
+    a.G = h->G;
+    a.rank = h->rank;
+    a.TB = h->TB;
+    a.T = h->T;
+    a.W = h->W;
+    a.L = h->L;
+    a.rc2_skin = h->rc2 * (1.0 + 1e-10);
+    return a;
+}
+
+N3Args n3_args(ljmd_t *h)
+{
+    N3Args a;
+    a.pos = h->d_pos;
+    a.mask = h->d_mask;
+    a.slab_i = h->d_slab;
+    a.slab_j = h->d_slab_j;
+    a.flag_j = h->d_flag_j;
+    a.wg_part = h->d_wg_part;
+    a.P = h->P;
+    a.G = h->G;
+    a.rank = h->rank;
+    a.TB = h->TB;
+    a.T = h->T;
+    a.W = h->W;
+    a.NG = h->NG;
+    a.NGown = h->NG;
+    a.Dmax = h->Dmax;
+    a.Q = h->Q;
+    a.dchunk = h->dchunk;
+    a.L = h->L;
+    a.invL = h->invL;
+    a.rc2 = h->rc2;
+    return a;
+}
+
+IntegrateArgs integrate_args(ljmd_t *h, int nslab, bool n3 = false)
 {
     IntegrateArgs a;
+    a.slab_j = n3 ? h->d_slab_j : nullptr;
+    a.flag_j = n3 ? h->d_flag_j : nullptr;
+    a.NG = h->NG;
+    a.Dmax = h->Dmax;
+    a.Q = h->Q;
     a.r = own_block(h);
     a.ru = h->d_ru;
     a.v = h->d_v;
     a.a = h->d_a;
     a.slab = h->d_slab;
     a.ke_part = h->d_ke_part;
-    a.rows = h->shard;
-    a.shard = h->shard;
-    a.nslab = h->nslab;
+    a.rows = h->P;
+    a.P = h->P;
+    a.nslab = nslab;
     a.L = h->L;
     a.invL = h->invL;
     a.dt = h->dt;
@@ -135,24 +217,25 @@ IntegrateArgs integrate_args(ljmd_t *h)
     return a;
 }
 
-FinalizeArgs finalize_args(ljmd_t *h, bool with_ke)
+FinalizeArgs finalize_args(ljmd_t *h, int n_wg, bool with_ke, double pair_scale)
 {
     FinalizeArgs a;
+    a.pair_scale = pair_scale;
     a.wg_part = h->d_wg_part;
     a.ke_part = h->d_ke_part;
     a.ring = h->d_ring;
     a.ring_pos = h->d_ring_pos;
-    a.n_wg = h->n_wg;
+    a.n_wg = n_wg;
     a.n_ke = with_ke ? h->n_ke : 0;
     a.ring_cap = kRingCap;
     return a;
 }
 
-EventQuad *next_events(ljmd_t *h)
+EventSet *next_events(ljmd_t *h)
 {
     if (!h->profiling || h->ev_used >= (size_t)kMaxProfiledLaunches) return nullptr;
     if (h->ev_used == h->ev_pool.size()) {
-        EventQuad q;
+        EventSet q;
         for (auto &e : q.e)
             if (hipEventCreate(&e) != hipSuccess) return nullptr;
         h->ev_pool.push_back(q);
@@ -160,27 +243,90 @@ EventQuad *next_events(ljmd_t *h)
     return &h->ev_pool[h->ev_used++];
 }
 
-bool fast_mic(const ljmd_t *h) { return h->rc_allows_fast_mic && h->positions_compact; }
+// Spatial re-ordering of the owned shard: keys -> stable radix sort -> gather r, ru, v (+ a when
+// asked) and compose the slot->original permutation.  Performance only (ljmd_sort.hip).
+int resort(ljmd_t *h, bool with_accel)
+{
+    SortArgs sa;
+    sa.r = own_block(h);
+    sa.keys = h->d_keys;
+    sa.idx = h->d_idx;
+    sa.S = h->S;
+    sa.P = h->P;
+    sa.ncell = h->ncell;
+    sa.L = h->L;
+    LJMD_HIP(h, launch_sort_keys(sa, h->stream));
+    LJMD_HIP(h, sort_pairs(h->d_cub, h->cub_bytes, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2, h->P, h->stream));
+    const size_t bytes3 = 3 * (size_t)h->P * sizeof(double);
+    double *sets[4] = {own_block(h), h->d_ru, h->d_v, h->d_a};
+    for (int k = 0; k < (with_accel ? 4 : 3); ++k) {
+        LJMD_HIP(h, launch_gather3(sets[k], h->d_tmp3, h->d_idx2, h->P, h->stream));
+        LJMD_HIP(h, hipMemcpyAsync(sets[k], h->d_tmp3, bytes3, hipMemcpyDeviceToDevice, h->stream));
+    }
+    LJMD_HIP(h, launch_gather_perm(h->d_perm, h->d_perm2, h->d_idx2, h->P, h->stream));
+    std::swap(h->d_perm, h->d_perm2);
+    h->perm_dirty = true;
+    h->steps_since_sort = 0;
+    return LJMD_OK;
+}
+
+int refresh_perm(ljmd_t *h)
+{
+    if (!h->perm_dirty) return LJMD_OK;
+    LJMD_HIP(h, hipMemcpyAsync(h->h_perm.data(), h->d_perm, (size_t)h->P * sizeof(int), hipMemcpyDeviceToHost,
+                               h->stream));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    h->perm_dirty = false;
+    return LJMD_OK;
+}
 
 // forces on the owned rows from the exchange buffer; a <- 24 * sum(slabs)
-int enqueue_forces(ljmd_t *h, bool kick, EventQuad *q)
+int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
 {
+    const bool fast = fast_path_ok(h);
     if (q) LJMD_HIP(h, hipEventRecord(q->e[1], h->stream));
-    LJMD_HIP(h, launch_pair_rows(pair_args(h), fast_mic(h), h->pair_grid, h->stream));
-    if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
-    LJMD_HIP(h, launch_reduce_kick(integrate_args(h), kick, h->stream));
-    LJMD_HIP(h, launch_finalize(finalize_args(h, kick), h->stream));
+    int nslab, n_wg;
+    bool n3 = false;
+    if (fast) {
+        const GeometryArgs ga = geometry_args(h);
+        LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
+        LJMD_HIP(h, launch_tile_mask(ga, h->stream));
+        if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
+        if (h->use_n3) {
+            const dim3 grid((h->NG + kWavesPerBlock - 1) / kWavesPerBlock, h->nslab_n);
+            LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->stream));
+            nslab = h->nslab_n;
+            n_wg = grid.x * grid.y;
+            n3 = true;
+        } else {
+            const dim3 grid(h->TB / kWavesPerBlock, h->nslab_t);
+            LJMD_HIP(h, launch_pair_tiles(pair_args(h, true), grid, h->stream));
+            nslab = h->nslab_t;
+            n_wg = grid.x * grid.y;
+        }
+    } else {
+        if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
+        const dim3 grid(h->P / kBlock, h->nslab_g);
+        LJMD_HIP(h, launch_pair_rows_generic(pair_args(h, false), grid, h->stream));
+        nslab = h->nslab_g;
+        n_wg = grid.x * grid.y;
+    }
     if (q) LJMD_HIP(h, hipEventRecord(q->e[3], h->stream));
+    LJMD_HIP(h, launch_reduce_kick(integrate_args(h, nslab, n3), kick, h->stream));
+    LJMD_HIP(h, launch_finalize(finalize_args(h, n_wg, kick, n3 ? 1.0 : 0.5), h->stream));
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[4], h->stream));
     h->ring_issued++;
     h->have_accel = true;
     return LJMD_OK;
 }
 
-int enqueue_drift(ljmd_t *h, EventQuad *q)
+int enqueue_drift(ljmd_t *h, EventSet *q)
 {
     if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
-    LJMD_HIP(h, launch_drift_kick(integrate_args(h), h->stream));
+    LJMD_HIP(h, launch_drift_kick(integrate_args(h, 1), h->stream));
     h->positions_compact = true;  // freshly wrapped into [0, L]
+    if (h->sort_enabled && fast_path_ok(h) && ++h->steps_since_sort >= h->resort_every)
+        return resort(h, false);  // a(t) is dead after the drift/kick: K3 rewrites it
     return LJMD_OK;
 }
 
@@ -190,8 +336,7 @@ int fetch_ring(ljmd_t *h, unsigned count)
     if (count > h->ring_issued - h->ring_consumed)
         return fail(h, LJMD_ERR_STATE, "requested %u step records but only %u are pending", count,
                     h->ring_issued - h->ring_consumed);
-    // skip older unread records (caller asked for the LAST `count`)
-    h->ring_consumed = h->ring_issued - count;
+    h->ring_consumed = h->ring_issued - count;  // older unread records are dropped
     unsigned done = 0;
     while (done < count) {
         const unsigned pos = (h->ring_consumed + done) % kRingCap;
@@ -219,9 +364,7 @@ void combine_one(const ljmd_t *h, const double *recs, int n_ranks, double *epot,
         ky += r[3];
         kz += r[4];
     }
-    // every unordered pair was visited twice by the full-matrix rows -> exact halving
-    s12 *= 0.5;
-    s6 *= 0.5;
+    // (the kernels already normalised s12, s6 to unordered-pair sums: FinalizeArgs::pair_scale)
     if (epot) *epot = 4.0 * (s12 - s6) + h->tail_e;                   // :140,:188,:221
     if (d_epot) *d_epot = 24.0 * (-2.0 * s12 + s6) + h->tail_d;       // :143,:177,:192,:222
     if (dd_epot) *dd_epot = 24.0 * (26.0 * s12 - 7.0 * s6) + h->tail_dd;  // :178,:193,:223
@@ -235,19 +378,38 @@ void release(ljmd_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &q : h->ev_pool)
         for (auto &e : q.e) (void)hipEventDestroy(e);
-    (void)hipFree(h->d_pos);
-    (void)hipFree(h->d_ru);
-    (void)hipFree(h->d_v);
-    (void)hipFree(h->d_a);
-    (void)hipFree(h->d_slab);
-    (void)hipFree(h->d_wg_part);
-    (void)hipFree(h->d_ke_part);
-    (void)hipFree(h->d_ring);
-    (void)hipFree(h->d_ring_pos);
+    void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
+                   h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
+                   h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j};
+    for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+// stage[ax*P + slot] for the owned shard, slot order = current device order
+void stage_permuted(ljmd_t *h, const double *x, const double *y, const double *z, size_t off, double pad)
+{
+    const double *src[3] = {x + off, y + off, z + off};
+    for (int ax = 0; ax < 3; ++ax) {
+        double *dst = h->h_stage + (size_t)ax * h->P;
+        for (int i = 0; i < h->P; ++i) {
+            const int o = h->h_perm[i];
+            dst[i] = (o < h->S) ? src[ax][o] : pad;
+        }
+    }
+}
+
+int upload_shard3(ljmd_t *h, double *dst, const double *x, const double *y, const double *z)
+{
+    int rc_ = refresh_perm(h);
+    if (rc_ != LJMD_OK) return rc_;
+    stage_permuted(h, x, y, z, (size_t)h->rank * h->S, 0.0);
+    LJMD_HIP(h, hipMemcpyAsync(dst, h->h_stage, 3 * (size_t)h->P * sizeof(double), hipMemcpyHostToDevice,
+                               h->stream));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
+    return LJMD_OK;
 }
 
 }  // namespace
@@ -255,7 +417,7 @@ void release(ljmd_t *h)
 // ---------------------------------------------------------------------------
 extern "C" {
 
-const char *ljmd_version(void) { return "ljmd 0.1.0 gfx950"; }
+const char *ljmd_version(void) { return "ljmd 0.2.0 gfx950"; }
 
 int32_t ljmd_device_count(void)
 {
@@ -294,9 +456,13 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     ljmd_t *h = new (std::nothrow) ljmd;
     if (!h) return fail(nullptr, LJMD_ERR_ALLOC, "ljmd_create: out of host memory");
     h->n = n;
-    h->n_ranks = n_ranks;
+    h->G = n_ranks;
     h->rank = rank;
-    h->shard = n / n_ranks;
+    h->S = n / n_ranks;
+    h->P = ((h->S + kBlock - 1) / kBlock) * kBlock;
+    h->TB = h->P / kTile;
+    h->T = h->G * h->TB;
+    h->W = (h->T + 63) / 64;
     h->device = device;
     h->mode = precision_mode;
     // compute_derived_params, md_types.f90:137-159, same expressions
@@ -317,43 +483,83 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->tail_d = 2.0 * tf * (-2.0 / (3.0 * rc6) + 1.0);
         h->tail_dd = 2.0 * tf * (26.0 / (3.0 * rc6) - 7.0);
     }
-    h->rc_allows_fast_mic = rc <= (1.0 - 1e-9) * 0.5 * box_length;
+    h->rc_allows_fast = rc <= (1.0 - 1e-9) * 0.5 * box_length;
+    h->sort_enabled = env_int("LJMD_SORT", 1) != 0;
+    h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
+    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", 10));
+    h->ncell = std::max(1, std::min(1023, (int)std::floor(box_length / 1.2)));
 
-    // launch geometry of the pair kernel: rows x j-chunks >= kTargetWorkgroups
-    const int row_tiles = (h->shard + kBlock - 1) / kBlock;
-    int nslab = (kTargetWorkgroups + row_tiles - 1) / row_tiles;
-    nslab = std::max(1, std::min(nslab, (n + 63) / 64));
-    h->chunk = (n + nslab - 1) / nslab;
-    h->chunk = ((h->chunk + 7) / 8) * 8;
-    h->nslab = (n + h->chunk - 1) / h->chunk;
-    h->pair_grid = dim3(row_tiles, h->nslab);
-    h->n_wg = row_tiles * h->nslab;
-    h->n_ke = row_tiles;
+    // launch geometry: rows x slices >= kTargetWorkgroups
+    const int row_blocks = h->P / kBlock;
+    {   // generic kernel: slices over the n real particles
+        int ns = (kTargetWorkgroups + row_blocks - 1) / row_blocks;
+        ns = std::max(1, std::min(ns, (n + 63) / 64));
+        h->chunk_g = ((n + ns - 1) / ns + 7) / 8 * 8;
+        h->nslab_g = (n + h->chunk_g - 1) / h->chunk_g;
+    }
+    {   // tile kernel: slices over the W mask words
+        int ns = (kTargetWorkgroups + row_blocks - 1) / row_blocks;
+        ns = std::max(1, std::min(ns, h->W));
+        h->chunk_t = (h->W + ns - 1) / ns;
+        h->nslab_t = (h->W + h->chunk_t - 1) / h->chunk_t;
+    }
+    {   // Newton-3 kernel: single rank, enough row groups to fill the chip
+        h->NG = h->T / kRowTiles;
+        h->Dmax = h->NG / 2;
+        h->Q = (h->Dmax + 1) * kRowTiles;
+        const int n3_min = env_int("LJMD_N3_MIN_N", 16384);
+        h->use_n3 = (h->G == 1) && env_int("LJMD_N3", 1) != 0 && n >= n3_min;
+        int ns = (8192 + h->NG - 1) / h->NG;
+        ns = std::max(1, std::min(ns, h->Dmax + 1));
+        h->dchunk = (h->Dmax + 1 + ns - 1) / ns;
+        h->nslab_n = (h->Dmax + 1 + h->dchunk - 1) / h->dchunk;
+    }
+    const int nslab_max = std::max(std::max(h->nslab_g, h->nslab_t), h->use_n3 ? h->nslab_n : 1);
+    const int n_wg_max = std::max(row_blocks * std::max(h->nslab_g, h->nslab_t),
+                                  ((h->NG + kWavesPerBlock - 1) / kWavesPerBlock) * h->nslab_n);
+    h->n_ke = row_blocks;
+    h->h_perm.resize(h->P);
+    for (int i = 0; i < h->P; ++i) h->h_perm[i] = i;
 
-    int rc_ = LJMD_OK;
     auto body = [&]() -> int {
         LJMD_HIP(h, hipSetDevice(device));
         LJMD_HIP(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        const size_t S3 = 3 * (size_t)h->shard * sizeof(double);
-        LJMD_HIP(h, hipMalloc(&h->d_pos, 3 * (size_t)n * sizeof(double)));
-        LJMD_HIP(h, hipMalloc(&h->d_ru, S3));
-        LJMD_HIP(h, hipMalloc(&h->d_v, S3));
-        LJMD_HIP(h, hipMalloc(&h->d_a, S3));
-        LJMD_HIP(h, hipMalloc(&h->d_slab, S3 * h->nslab));
-        LJMD_HIP(h, hipMalloc(&h->d_wg_part, 2 * (size_t)h->n_wg * sizeof(double)));
+        const size_t P3 = 3 * (size_t)h->P * sizeof(double);
+        LJMD_HIP(h, hipMalloc(&h->d_pos, P3 * h->G));
+        LJMD_HIP(h, hipMalloc(&h->d_ru, P3));
+        LJMD_HIP(h, hipMalloc(&h->d_v, P3));
+        LJMD_HIP(h, hipMalloc(&h->d_a, P3));
+        LJMD_HIP(h, hipMalloc(&h->d_tmp3, P3));
+        LJMD_HIP(h, hipMalloc(&h->d_slab, P3 * nslab_max));
+        LJMD_HIP(h, hipMalloc(&h->d_wg_part, 2 * (size_t)n_wg_max * sizeof(double)));
+        if (h->use_n3) {
+            LJMD_HIP(h, hipMalloc(&h->d_slab_j, (size_t)h->NG * h->Q * 3 * kTile * sizeof(double)));
+            LJMD_HIP(h, hipMalloc(&h->d_flag_j, (size_t)h->NG * h->Q));
+            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, (size_t)h->NG * h->Q, h->stream));
+        }
         LJMD_HIP(h, hipMalloc(&h->d_ke_part, 3 * (size_t)h->n_ke * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring, (size_t)kRingCap * kPartialStride * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring_pos, sizeof(unsigned)));
+        LJMD_HIP(h, hipMalloc(&h->d_bbox, (size_t)h->T * kBoxStride * sizeof(double)));
+        LJMD_HIP(h, hipMalloc(&h->d_mask, (size_t)h->TB * h->W * sizeof(uint64_t)));
+        LJMD_HIP(h, hipMalloc(&h->d_keys, (size_t)h->P * sizeof(unsigned)));
+        LJMD_HIP(h, hipMalloc(&h->d_keys2, (size_t)h->P * sizeof(unsigned)));
+        LJMD_HIP(h, hipMalloc(&h->d_idx, (size_t)h->P * sizeof(int)));
+        LJMD_HIP(h, hipMalloc(&h->d_idx2, (size_t)h->P * sizeof(int)));
+        LJMD_HIP(h, hipMalloc(&h->d_perm, (size_t)h->P * sizeof(int)));
+        LJMD_HIP(h, hipMalloc(&h->d_perm2, (size_t)h->P * sizeof(int)));
+        h->cub_bytes = sort_temp_bytes(h->P);
+        LJMD_HIP(h, hipMalloc(&h->d_cub, std::max<size_t>(h->cub_bytes, 16)));
         LJMD_HIP(h, hipMemsetAsync(h->d_ring_pos, 0, sizeof(unsigned), h->stream));
-        LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, S3, h->stream));
+        LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, P3, h->stream));
         LJMD_HIP(h, hipMemsetAsync(h->d_ke_part, 0, 3 * (size_t)h->n_ke * sizeof(double), h->stream));
-        LJMD_HIP(h, hipHostMalloc(&h->h_stage, 3 * (size_t)n * sizeof(double), hipHostMallocDefault));
+        LJMD_HIP(h, hipHostMalloc(&h->h_stage, P3 * h->G, hipHostMallocDefault));
         LJMD_HIP(h, hipHostMalloc(&h->h_ring, (size_t)kRingCap * kPartialStride * sizeof(double),
                                   hipHostMallocDefault));
         LJMD_HIP(h, hipStreamSynchronize(h->stream));
         return LJMD_OK;
     };
-    rc_ = body();
+    const int rc_ = body();
     if (rc_ != LJMD_OK) {
         g_last_error = h->err;
         release(h);
@@ -367,19 +573,6 @@ void ljmd_destroy(ljmd_t *h) { release(h); }
 
 // ---- state transfer --------------------------------------------------------
 
-static int upload_shard3(ljmd_t *h, double *dst, const double *x, const double *y, const double *z,
-                         bool global_arrays)
-{
-    // x,y,z: length n (global_arrays) or shard; packs [3][shard] of the owned rows
-    const size_t S = h->shard, off = global_arrays ? (size_t)h->rank * S : 0;
-    std::memcpy(h->h_stage, x + off, S * sizeof(double));
-    std::memcpy(h->h_stage + S, y + off, S * sizeof(double));
-    std::memcpy(h->h_stage + 2 * S, z + off, S * sizeof(double));
-    LJMD_HIP(h, hipMemcpyAsync(dst, h->h_stage, 3 * S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    LJMD_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
-    return LJMD_OK;
-}
-
 int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz,
                    const double *vx, const double *vy, const double *vz)
 {
@@ -387,14 +580,15 @@ int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *
     if (!rx || !ry || !rz || !vx || !vy || !vz)
         return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_set_state: NULL array");
     LJMD_HIP(h, hipSetDevice(h->device));
-    const size_t S = h->shard;
-    // all n positions into the exchange buffer, shard-blocked; track the coordinate spread
+    const size_t S = h->S, P = h->P;
+    // all n positions into the exchange buffer in original order, NaN on the padding;
+    // track the coordinate spread (fast-path precondition (a), ljmd_kernels.hip)
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     const double *src[3] = {rx, ry, rz};
     bool finite = true;
-    for (int g = 0; g < h->n_ranks; ++g)
+    for (int g = 0; g < h->G; ++g)
         for (int ax = 0; ax < 3; ++ax) {
-            double *dst = h->h_stage + ((size_t)g * 3 + ax) * S;
+            double *dst = h->h_stage + ((size_t)g * 3 + ax) * P;
             const double *s = src[ax] + (size_t)g * S;
             for (size_t i = 0; i < S; ++i) {
                 const double x = s[i];
@@ -403,21 +597,29 @@ int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *
                 hi[ax] = std::max(hi[ax], x);
                 finite = finite && std::isfinite(x);
             }
+            for (size_t i = S; i < P; ++i) dst[i] = NAN;
         }
     h->positions_compact = finite;
     for (int ax = 0; ax < 3; ++ax)
         if (!(hi[ax] - lo[ax] < 2.4 * h->L)) h->positions_compact = false;
-    LJMD_HIP(h, hipMemcpyAsync(h->d_pos, h->h_stage, 3 * (size_t)h->n * sizeof(double),
-                               hipMemcpyHostToDevice, h->stream));
-    // ru <- r (md_simulation_program.f90:229-231), own shard
-    LJMD_HIP(h, hipMemcpyAsync(h->d_ru, own_block(h), 3 * S * sizeof(double), hipMemcpyDeviceToDevice,
+    LJMD_HIP(h, hipMemcpyAsync(h->d_pos, h->h_stage, 3 * P * h->G * sizeof(double), hipMemcpyHostToDevice,
                                h->stream));
-    LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, 3 * S * sizeof(double), h->stream));
+    // ru <- r (md_simulation_program.f90:229-231), own shard
+    LJMD_HIP(h, hipMemcpyAsync(h->d_ru, own_block(h), 3 * P * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, 3 * P * sizeof(double), h->stream));
     LJMD_HIP(h, hipStreamSynchronize(h->stream));
-    int rc_ = upload_shard3(h, h->d_v, vx, vy, vz, true);
+    // slot order is the original order again
+    for (int i = 0; i < h->P; ++i) h->h_perm[i] = i;
+    LJMD_HIP(h, hipMemcpyAsync(h->d_perm, h->h_perm.data(), P * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    h->perm_dirty = false;
+    int rc_ = upload_shard3(h, h->d_v, vx, vy, vz);
     if (rc_ != LJMD_OK) return rc_;
     h->have_state = true;
     h->have_accel = false;
+    if (h->sort_enabled && fast_path_ok(h)) {
+        rc_ = resort(h, false);   // accelerations are all zero at this point
+        if (rc_ != LJMD_OK) return rc_;
+    }
     return LJMD_OK;
 }
 
@@ -425,8 +627,9 @@ int ljmd_set_accel(ljmd_t *h, const double *ax, const double *ay, const double *
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_set_accel: NULL handle");
     if (!ax || !ay || !az) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_set_accel: NULL array");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_set_accel: call ljmd_set_state first");
     LJMD_HIP(h, hipSetDevice(h->device));
-    int rc_ = upload_shard3(h, h->d_a, ax, ay, az, true);
+    const int rc_ = upload_shard3(h, h->d_a, ax, ay, az);
     if (rc_ == LJMD_OK) h->have_accel = true;
     return rc_;
 }
@@ -435,8 +638,9 @@ int ljmd_set_unwrapped(ljmd_t *h, const double *ux, const double *uy, const doub
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_set_unwrapped: NULL handle");
     if (!ux || !uy || !uz) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_set_unwrapped: NULL array");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_set_unwrapped: call ljmd_set_state first");
     LJMD_HIP(h, hipSetDevice(h->device));
-    return upload_shard3(h, h->d_ru, ux, uy, uz, true);
+    return upload_shard3(h, h->d_ru, ux, uy, uz);
 }
 
 int ljmd_get_state(ljmd_t *h, double *rx, double *ry, double *rz, double *ux, double *uy, double *uz,
@@ -445,16 +649,23 @@ int ljmd_get_state(ljmd_t *h, double *rx, double *ry, double *rz, double *ux, do
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_get_state: NULL handle");
     if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_get_state: no state has been set");
     LJMD_HIP(h, hipSetDevice(h->device));
-    const size_t S = h->shard;
+    int rc_ = refresh_perm(h);
+    if (rc_ != LJMD_OK) return rc_;
+    const size_t P = h->P;
     const double *srcs[4] = {own_block(h), h->d_ru, h->d_v, h->d_a};
     double *dsts[4][3] = {{rx, ry, rz}, {ux, uy, uz}, {vx, vy, vz}, {ax, ay, az}};
     for (int w = 0; w < 4; ++w) {
         if (!dsts[w][0] && !dsts[w][1] && !dsts[w][2]) continue;
-        LJMD_HIP(h, hipMemcpyAsync(h->h_stage, srcs[w], 3 * S * sizeof(double), hipMemcpyDeviceToHost,
-                                   h->stream));
+        LJMD_HIP(h, hipMemcpyAsync(h->h_stage, srcs[w], 3 * P * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         LJMD_HIP(h, hipStreamSynchronize(h->stream));
-        for (int k = 0; k < 3; ++k)
-            if (dsts[w][k]) std::memcpy(dsts[w][k], h->h_stage + k * S, S * sizeof(double));
+        for (int k = 0; k < 3; ++k) {
+            if (!dsts[w][k]) continue;
+            const double *st = h->h_stage + k * P;
+            for (int i = 0; i < h->P; ++i) {
+                const int o = h->h_perm[i];
+                if (o < h->S) dsts[w][k][o] = st[i];   // slot -> original index of the shard
+            }
+        }
     }
     return LJMD_OK;
 }
@@ -465,10 +676,10 @@ int ljmd_compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_compute_forces: NULL handle");
     if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_compute_forces: no state has been set");
-    if (h->n_ranks != 1)
+    if (h->G != 1)
         return fail(h, LJMD_ERR_STATE, "ljmd_compute_forces: sharded engine; use ljmd_forces_partial");
     LJMD_HIP(h, hipSetDevice(h->device));
-    EventQuad *q = next_events(h);
+    EventSet *q = next_events(h);
     if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
     int rc_ = enqueue_forces(h, false, q);
     if (rc_ != LJMD_OK) return rc_;
@@ -487,14 +698,14 @@ int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, dou
     if (!h->have_accel)
         return fail(h, LJMD_ERR_STATE,
                     "ljmd_verlet_steps: accelerations not initialised (call ljmd_compute_forces first)");
-    if (h->n_ranks != 1)
+    if (h->G != 1)
         return fail(h, LJMD_ERR_STATE, "ljmd_verlet_steps: sharded engine; use ljmd_step_begin/finish");
     LJMD_HIP(h, hipSetDevice(h->device));
     int done = 0;
     while (done < nsteps) {
         const int batch = std::min<int>(nsteps - done, (int)kRingCap);
         for (int s = 0; s < batch; ++s) {
-            EventQuad *q = next_events(h);
+            EventSet *q = next_events(h);
             int rc_ = enqueue_drift(h, q);
             if (rc_ != LJMD_OK) return rc_;
             rc_ = enqueue_forces(h, true, q);
@@ -516,7 +727,7 @@ int ljmd_kinetic_energy(ljmd_t *h, double *ekin)
     if (!h || !ekin) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_kinetic_energy: NULL argument");
     if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_kinetic_energy: no state has been set");
     LJMD_HIP(h, hipSetDevice(h->device));
-    LJMD_HIP(h, launch_kinetic_fused(integrate_args(h), h->stream));
+    LJMD_HIP(h, launch_kinetic_fused(integrate_args(h, 1), h->stream));
     std::vector<double> part(3 * (size_t)h->n_ke);
     LJMD_HIP(h, hipMemcpyAsync(part.data(), h->d_ke_part, part.size() * sizeof(double),
                                hipMemcpyDeviceToHost, h->stream));
@@ -532,17 +743,17 @@ int ljmd_kinetic_energy(ljmd_t *h, double *ekin)
 int ljmd_shard_range(const ljmd_t *h, int32_t *i0, int32_t *i1)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_shard_range: NULL handle");
-    if (i0) *i0 = h->rank * h->shard;
-    if (i1) *i1 = (h->rank + 1) * h->shard;
+    if (i0) *i0 = h->rank * h->S;
+    if (i1) *i1 = (h->rank + 1) * h->S;
     return LJMD_OK;
 }
 
 void *ljmd_exchange_buffer(ljmd_t *h, int64_t *n_total, int64_t *own_off, int64_t *own_cnt)
 {
     if (!h) return nullptr;
-    if (n_total) *n_total = 3 * (int64_t)h->n;
-    if (own_off) *own_off = (int64_t)h->rank * 3 * h->shard;
-    if (own_cnt) *own_cnt = 3 * (int64_t)h->shard;
+    if (n_total) *n_total = 3 * (int64_t)h->P * h->G;
+    if (own_off) *own_off = (int64_t)h->rank * 3 * h->P;
+    if (own_cnt) *own_cnt = 3 * (int64_t)h->P;
     return h->d_pos;
 }
 
@@ -557,7 +768,7 @@ void *ljmd_device_ptr(ljmd_t *h, int32_t which, int32_t axis)
         case LJMD_A: base = h->d_a; break;
         default: return nullptr;
     }
-    return base + (size_t)axis * h->shard;
+    return base + (size_t)axis * h->P;
 }
 
 void *ljmd_stream(ljmd_t *h) { return h ? (void *)h->stream : nullptr; }
@@ -568,7 +779,7 @@ int ljmd_step_begin(ljmd_t *h)
     if (!h->have_state || !h->have_accel)
         return fail(h, LJMD_ERR_STATE, "ljmd_step_begin: state/accelerations not initialised");
     LJMD_HIP(h, hipSetDevice(h->device));
-    return enqueue_drift(h, nullptr);
+    return enqueue_drift(h, next_events(h));
 }
 
 int ljmd_step_finish(ljmd_t *h)
@@ -576,8 +787,8 @@ int ljmd_step_finish(ljmd_t *h)
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_step_finish: NULL handle");
     if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_step_finish: no state has been set");
     LJMD_HIP(h, hipSetDevice(h->device));
-    EventQuad *q = next_events(h);
-    if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
+    // pairs with the event set taken by ljmd_step_begin (the last one handed out)
+    EventSet *q = (h->profiling && h->ev_used > 0) ? &h->ev_pool[h->ev_used - 1] : nullptr;
     return enqueue_forces(h, true, q);
 }
 
@@ -619,24 +830,22 @@ int ljmd_profile_enable(ljmd_t *h, int32_t on)
     return LJMD_OK;
 }
 
-int ljmd_profile_read(ljmd_t *h, double *force_ms_avg, double *integrate_ms_avg, int32_t *launches)
+int ljmd_profile_read(ljmd_t *h, double *ms_avg, int32_t *launches)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_read: NULL handle");
     LJMD_HIP(h, hipSetDevice(h->device));
     LJMD_HIP(h, hipStreamSynchronize(h->stream));
-    double f = 0.0, g = 0.0;
-    for (size_t k = 0; k < h->ev_used; ++k) {
-        float ms = 0.f;
-        LJMD_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[k].e[1], h->ev_pool[k].e[2]));
-        f += ms;
-        LJMD_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[k].e[0], h->ev_pool[k].e[1]));
-        g += ms;
-        LJMD_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[k].e[2], h->ev_pool[k].e[3]));
-        g += ms;
-    }
+    double acc[4] = {0, 0, 0, 0};  // pair kernel, geometry pre-pass, drift/kick, reduce+finalize
+    const int from[4] = {2, 1, 0, 3}, to[4] = {3, 2, 1, 4};
+    for (size_t k = 0; k < h->ev_used; ++k)
+        for (int c = 0; c < 4; ++c) {
+            float ms = 0.f;
+            LJMD_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[k].e[from[c]], h->ev_pool[k].e[to[c]]));
+            acc[c] += ms;
+        }
     const double cnt = h->ev_used ? (double)h->ev_used : 1.0;
-    if (force_ms_avg) *force_ms_avg = f / cnt;
-    if (integrate_ms_avg) *integrate_ms_avg = g / cnt;
+    if (ms_avg)
+        for (int c = 0; c < 4; ++c) ms_avg[c] = acc[c] / cnt;
     if (launches) *launches = (int32_t)h->ev_used;
     h->ev_used = 0;
     return LJMD_OK;

@@ -1,4 +1,12 @@
 // ljmd_internal.h -- argument blocks shared by the kernels and the C-ABI host code.
+//
+// HBM layout (all fp64, structure of arrays):
+//   n      total particles, G ranks, S = n / G particles per rank ("shard"),
+//   P      axis stride = S rounded up to a multiple of kBlock (256); slots S..P-1 of every
+//          axis array are padding: position = NaN (never passes r^2 < rc^2), v = a = 0.
+//   pos    exchange buffer [G][3][P]: block g = x[P] y[P] z[P] of rank g's particles.
+//   ru,v,a [3][P] of the owned shard.
+//   tiles  64 consecutive slots; TB = P / 64 tiles per rank block, T = G * TB tiles.
 #ifndef LJMD_INTERNAL_H
 #define LJMD_INTERNAL_H
 
@@ -9,44 +17,102 @@ namespace ljmdk {
 
 constexpr int kBlock = 256;                 // threads per workgroup = 4 wave64
 constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kTile = 64;                   // particles per tile = one wave
+constexpr int kRowTiles = 4;                // tiles per Newton-3 row group (particles per lane)
 constexpr int kPartialStride = 8;           // doubles per per-rank per-step partial record
+constexpr int kBoxStride = 8;               // doubles per tile bounding box (lo xyz, hi xyz, 2 pad)
 
 struct PairArgs {
-    const double *pos;   // exchange buffer: all n positions, shard-blocked SoA
-    double *slab;        // [nslab][3][shard] raw partial accelerations of the owned rows
-    double *wg_part;     // [n workgroups][2] = s12, s6
-    int n;               // total particles
-    int shard;           // particles per rank (n / n_ranks)
+    const double *pos;      // exchange buffer [G][3][P]
+    double *slab;           // [nslab][3][P] raw partial accelerations of the owned rows
+    double *wg_part;        // [n workgroups][2] = s12, s6
+    const uint64_t *mask;   // [TB][W] bit (J) of row I set = tile pair must be evaluated
+    int n;                  // total particles
+    int S;                  // real particles per rank
+    int P;                  // padded axis stride
+    int G;                  // ranks
     int rank;
-    int row0;            // global index of the first owned row (= rank * shard)
-    int rows;            // owned rows (= shard)
-    int chunk;           // j per grid.y slice
+    int TB;                 // tiles per rank block
+    int T;                  // tiles in total
+    int W;                  // 64-bit mask words per row = ceil(T / 64)
+    int chunk;              // generic kernel: j slots per grid.y slice; tile kernel: mask words per slice
+    double L, invL, rc2;
+};
+
+// Newton-3 pair kernel (ljmd_kernels.hip: pair_n3_kernel).  Row group = kRowTiles (4) consecutive
+// tiles = 256 slots held by ONE wave, 4 particles per lane.  NG = T / 4 groups.  A row group A
+// owns the column groups B with cyclic offset d = (B - A) mod NG in [0, Dmax] (ties broken by
+// index), so every unordered pair of particles is evaluated exactly once on the whole machine.
+struct N3Args {
+    const double *pos;      // exchange buffer
+    const uint64_t *mask;   // [T rows][W] tile-pair mask (all row tiles, not only the owned ones)
+    double *slab_i;         // [nchunk][3][P] partial accelerations of the owned rows (row side)
+    double *slab_j;         // [NGown][Q][3][64] column-side partial accelerations, Q = (Dmax+1)*4
+    unsigned char *flag_j;  // [NGown][Q] 1 = slab_j block written this step
+    double *wg_part;        // [n workgroups][2]
+    int P, G, rank, TB, T, W;
+    int NG, NGown, Dmax, Q; // groups in total / owned by this rank
+    int dchunk;             // offsets d per grid.y slice
     double L, invL, rc2;
 };
 
 struct IntegrateArgs {
-    double *r;           // own block of the exchange buffer, axis stride = shard
-    double *ru, *v, *a;  // [3][shard]
-    const double *slab;  // [nslab][3][shard]
-    double *ke_part;     // [n blocks][3]
-    int rows, shard, nslab;
+    double *r;              // own block of the exchange buffer, axis stride = P
+    double *ru, *v, *a;     // [3][P]
+    const double *slab;     // [nslab][3][P]
+    double *ke_part;        // [n blocks][3]
+    // Newton-3 column-side slabs (NULL when the gather kernels produced the forces)
+    const double *slab_j;
+    const unsigned char *flag_j;
+    int NG, Dmax, Q;
+    int rows;               // = P (padding included: it integrates to NaN / 0 harmlessly)
+    int P, nslab;
     double L, invL, dt, dt_half, dt_sq_half;
 };
 
 struct FinalizeArgs {
     const double *wg_part;
     const double *ke_part;
-    double *ring;        // [ring_cap][kPartialStride]
-    unsigned *ring_pos;  // device counter, bumped once per finalize
+    double *ring;           // [ring_cap][kPartialStride]
+    unsigned *ring_pos;     // device counter, bumped once per finalize
     int n_wg, n_ke;
     unsigned ring_cap;
+    double pair_scale;      // 0.5 when every unordered pair was visited twice (gather kernels), 1 for Newton-3
 };
 
-hipError_t launch_pair_rows(const PairArgs &a, bool fast_mic, dim3 grid, hipStream_t s);
+struct GeometryArgs {
+    const double *pos;      // exchange buffer
+    double *bbox;           // [T][kBoxStride]
+    uint64_t *mask;         // [TB][W]
+    int P, G, rank, TB, T, W;
+    double L, rc2_skin;     // rc^2 * (1 + 1e-10): skip only when provably outside
+};
+
+struct SortArgs {
+    const double *r;        // own block [3][P]
+    unsigned *keys;         // [P]
+    int *idx;               // [P] iota
+    int S, P, ncell;
+    double L;
+};
+
+hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s);
+hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s);
 hipError_t launch_reduce_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, hipStream_t s);
+hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);
+hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s);
+
+// ljmd_sort.hip
+size_t sort_temp_bytes(int count);
+hipError_t launch_sort_keys(const SortArgs &a, hipStream_t s);
+hipError_t sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out,
+                      const int *idx_in, int *idx_out, int count, hipStream_t s);
+hipError_t launch_gather3(const double *src, double *dst, const int *idx, int P, hipStream_t s);
+hipError_t launch_gather_perm(const int *src, int *dst, const int *idx, int P, hipStream_t s);
 
 }  // namespace ljmdk
 #endif

@@ -9,6 +9,8 @@
 //   wrap                 scripts/physics/geometry_pbc.f90:39-59
 //   velocity Verlet      scripts/physics/verlet.f90:58-95
 //   unwrapped update     scripts/md_simulation_program.f90:339-353
+//
+// Layout conventions: ljmd_internal.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -25,6 +27,20 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));  // fmin ignores NaN
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
 }
 
 template <int NVAL>
@@ -48,39 +64,233 @@ __device__ __forceinline__ void block_sum(double (&v)[NVAL], double *lds /* [NVA
     }
 }
 
-// ---------------------------------------------------------------------------
-// One ordered pair (i <- j).  Accumulates the raw (prefactor-free) sums
-//   a_i += (2 u^6 - u^3) u * d          (= -dU_r * d * inv_r2, lj_potential_energy.f90:143-155)
-//   s12 += u^6 ,  s6 += u^3             (epot, d_epot, dd_epot are linear in these two)
-// with u = 1/r^2, d = minimum-image displacement.
-// FAST_MIC: d - L*rndne(d/L) with the product fused.  Valid, and bit-identical to
-// `d - L*dnint(d*invL)` for every pair that passes r^2 < rc^2, when |d/L| < 2.5
-// (L*n exact for |n| <= 2) and rc <= (1-1e-9) L/2 (a rounding tie of d/L means
-// |d_mic| ~ L/2 > rc).  The host selects it only under those conditions.
-// ---------------------------------------------------------------------------
-template <bool FAST_MIC>
-__device__ __forceinline__ double mic(double d, double L, double invL)
+// ===========================================================================
+// GENERIC pair kernel: exact for ANY finite input (positions far outside the box,
+// rc arbitrarily close to L/2).  Per pair it performs the reference's operations with
+// the reference's roundings -- dnint minimum image, (dx^2+dy^2)+dz^2, IEEE divide --
+// except that it accumulates the linear sums s12 = sum u^6, s6 = sum u^3 instead of
+// epot / d_epot / dd_epot separately.  Full matrix (each ordered pair), one thread per
+// row, j broadcast through scalar loads.  Used when the fast path's preconditions do
+// not hold (ljmd_capi.cpp: fast_path_ok).
+// ===========================================================================
+__global__ __launch_bounds__(kBlock) void pair_rows_generic_kernel(PairArgs a)
 {
-    if constexpr (FAST_MIC) {
-        return fma(-L, __builtin_rint(d * invL), d);
-    } else {
-        return d - L * __builtin_round(d * invL);
+    __shared__ double red[2 * kWavesPerBlock];
+    const int row = blockIdx.x * kBlock + threadIdx.x;         // slot in the owned block, < P
+    const double *own = a.pos + (size_t)a.rank * 3 * a.P;
+    const double xi = own[row], yi = own[a.P + row], zi = own[2 * (size_t)a.P + row];   // NaN on padding
+
+    double ax = 0.0, ay = 0.0, az = 0.0, s12 = 0.0, s6 = 0.0;
+
+    const int j0 = blockIdx.y * a.chunk;                       // index into the n real particles,
+    const int j1 = min(j0 + a.chunk, a.n);                     // rank-major: j = g * S + slot
+    for (int j = j0; j < j1;) {
+        const int g = j / a.S;
+        const int jl = j - g * a.S;
+        const int jend = min(j1, (g + 1) * a.S);
+        const double *bx = a.pos + (size_t)g * 3 * a.P;
+        const double *by = bx + a.P, *bz = by + a.P;
+        const int cnt = jend - j;
+        const bool own_block = (g == a.rank);
+        for (int k = 0; k < cnt; ++k) {
+            const double dx0 = xi - bx[jl + k], dy0 = yi - by[jl + k], dz0 = zi - bz[jl + k];
+            const double dx = dx0 - a.L * __builtin_round(dx0 * a.invL);      // geometry_pbc.f90:86
+            const double dy = dy0 - a.L * __builtin_round(dy0 * a.invL);
+            const double dz = dz0 - a.L * __builtin_round(dz0 * a.invL);
+            const double r2 = dx * dx + dy * dy + dz * dz;                    // :129
+            if (r2 < a.rc2 && !(own_block && jl + k == row)) {                // :132 + self exclusion
+                const double u = 1.0 / r2;                                    // :135
+                const double u3 = u * u * u;                                  // :136
+                const double u6 = u3 * u3;                                    // :137
+                s12 += u6;
+                s6 += u3;
+                const double mdu = 2.0 * u6 - u3;                             // = -dU_r, :143
+                ax += mdu * dx * u;                                           // :148-155
+                ay += mdu * dy * u;
+                az += mdu * dz * u;
+            }
+        }
+        j = jend;
+    }
+
+    double *s = a.slab + (size_t)blockIdx.y * 3 * a.P;
+    s[row] = ax;
+    s[a.P + row] = ay;
+    s[2 * (size_t)a.P + row] = az;
+    double v[2] = {s12, s6};
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        double *w = a.wg_part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        w[0] = v[0];
+        w[1] = v[1];
     }
 }
 
-template <bool FAST_MIC>
-__device__ __forceinline__ void pair_accum(double xi, double yi, double zi,
-                                           double xj, double yj, double zj,
-                                           double L, double invL, double rc2,
-                                           double &ax, double &ay, double &az,
-                                           double &s12, double &s6)
+// ===========================================================================
+// FAST path building blocks.  Preconditions (checked on the host):
+//   (a) every coordinate lies within a span < 2.4 L (true after any wrap), so |d/L| < 2.5,
+//       n = rndne(d/L) has |n| <= 2 and L*n is exact: fma(-L, n, d) == d - L*n rounded once,
+//       i.e. the same value the reference computes;
+//   (b) rc <= (1 - 1e-9) L/2: rndne and dnint differ only on exact ties of d/L, where
+//       |d_mic| ~ L/2 > rc, so the pair fails r^2 < rc^2 either way.
+// Differences from the reference per pair, all <= ~1 ulp of the term: r^2 and the force
+// use fma contraction, 1/r^2 is v_rcp_f64 + two Newton steps instead of the IEEE divide.
+// ===========================================================================
+__device__ __forceinline__ double mic_fast(double d, double L, double invL)
 {
-    const double dx = mic<FAST_MIC>(xi - xj, L, invL);
-    const double dy = mic<FAST_MIC>(yi - yj, L, invL);
-    const double dz = mic<FAST_MIC>(zi - zj, L, invL);
-    const double r2 = dx * dx + dy * dy + dz * dz;       // (dx^2 + dy^2) + dz^2 as :129
-    if (r2 < rc2) {                                      // strict <, NaN (padding) never passes
-        const double u = 1.0 / r2;                       // IEEE divide as :135
+    return fma(-L, __builtin_rint(d * invL), d);
+}
+
+__device__ __forceinline__ double rcp_newton(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);          // v_rcp_f64: ~24 good bits
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);                            // ~48 bits
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);                         // <= 1 ulp
+}
+
+template <bool EXCLUDE_SELF>
+__device__ __forceinline__ void pair_fast(double xi, double yi, double zi,
+                                          double xj, double yj, double zj,
+                                          double L, double invL, double rc2, bool is_self,
+                                          double &ax, double &ay, double &az,
+                                          double &s12, double &s6)
+{
+    const double dx = mic_fast(xi - xj, L, invL);
+    const double dy = mic_fast(yi - yj, L, invL);
+    const double dz = mic_fast(zi - zj, L, invL);
+    const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+    bool in = r2 < rc2;                                  // strict <; NaN (padding) never passes
+    if constexpr (EXCLUDE_SELF) in = in && !is_self;
+    if (in) {
+        const double u = rcp_newton(r2);
+        const double u3 = u * u * u;
+        const double u6 = u3 * u3;
+        s12 += u6;
+        s6 += u3;
+        const double g = fma(2.0, u6, -u3) * u;          // = -dU_r * inv_r2
+        ax = fma(g, dx, ax);
+        ay = fma(g, dy, ay);
+        az = fma(g, dz, az);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2 (gather, tiled): one wave per 64-particle row tile I (lane = particle), 4 waves per
+// workgroup.  The wave walks its row of the tile-pair mask (bit J set = tile J holds at
+// least one particle that can be within rc of tile I -- built by tile_mask_kernel from exact
+// bounding boxes) and for every set bit evaluates the 64 x 64 ordered pairs: the j
+// coordinates are wave-uniform, fetched with scalar loads and used as SGPR operands.
+// grid = (TB / 4, mask-word chunks).  Output as in the generic kernel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pair_tiles_kernel(PairArgs a)
+{
+    __shared__ double red[2 * kWavesPerBlock];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Il = blockIdx.x * kWavesPerBlock + wave;          // own tile, wave-uniform
+    const int I = a.rank * a.TB + Il;
+    const int row = Il * kTile + lane;
+    const double *own = a.pos + (size_t)a.rank * 3 * a.P;
+    const double xi = own[row], yi = own[a.P + row], zi = own[2 * (size_t)a.P + row];
+
+    double ax = 0.0, ay = 0.0, az = 0.0, s12 = 0.0, s6 = 0.0;
+
+    const uint64_t *mrow = a.mask + (size_t)Il * a.W;
+    const int w0 = blockIdx.y * a.chunk, w1 = min(w0 + a.chunk, a.W);
+    for (int w = w0; w < w1; ++w) {
+        uint64_t m = mrow[w];
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int J = w * 64 + b;
+            const int gj = (a.G == 1) ? 0 : J / a.TB;
+            const int jl = (J - gj * a.TB) * kTile;
+            const double *bx = a.pos + (size_t)gj * 3 * a.P + jl;
+            const double *by = bx + a.P, *bz = by + a.P;
+            // 8 j at a time: 3 x 64-byte scalar loads up front, then 8 pair evaluations on SGPR operands
+            if (J == I) {
+                for (int j0 = 0; j0 < kTile; j0 += 8) {
+                    double xj[8], yj[8], zj[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { xj[k] = bx[j0 + k]; yj[k] = by[j0 + k]; zj[k] = bz[j0 + k]; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        pair_fast<true>(xi, yi, zi, xj[k], yj[k], zj[k], a.L, a.invL, a.rc2, j0 + k == lane,
+                                        ax, ay, az, s12, s6);
+                }
+            } else {
+                for (int j0 = 0; j0 < kTile; j0 += 8) {
+                    double xj[8], yj[8], zj[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { xj[k] = bx[j0 + k]; yj[k] = by[j0 + k]; zj[k] = bz[j0 + k]; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        pair_fast<false>(xi, yi, zi, xj[k], yj[k], zj[k], a.L, a.invL, a.rc2, false,
+                                         ax, ay, az, s12, s6);
+                }
+            }
+        }
+    }
+
+    double *s = a.slab + (size_t)blockIdx.y * 3 * a.P;
+    s[row] = ax;
+    s[a.P + row] = ay;
+    s[2 * (size_t)a.P + row] = az;
+    double v[2] = {s12, s6};
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        double *w = a.wg_part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        w[0] = v[0];
+        w[1] = v[1];
+    }
+}
+
+// ===========================================================================
+// K2 (Newton-3): every unordered pair exactly once.
+//
+// One wave = one ROW GROUP of 4 tiles (256 particles, 4 per lane, positions and partial
+// accelerations in registers for the whole kernel).  For each COLUMN TILE (64 particles, one
+// per lane) the wave performs 64 steps: evaluate up to 4 pairs (one per row particle of the
+// lane) against the column particle currently held by the lane, add +f to the row side and
+// -f to the column side (lj_potential_energy.f90:153-159), then rotate the column particle
+// (position + partial acceleration, 12 dwords) one lane around the wave with DPP wave_ror.
+// After 64 steps every column particle is back in its home lane carrying the sum of the
+// forces from all 256 row particles; that block goes to slab_j[row group][column slot]
+// (one writer per block: no atomics, fixed summation order, reduced by reduce_kick_kernel).
+//
+// Ownership: row group A evaluates column group B = A + d (mod NG) for d = 0 .. Dmax = NG/2
+// (d = NG/2 only from the lower index), so each unordered pair of groups appears once; inside
+// the diagonal group (d = 0) tile pairs k < l are taken once and a tile against itself uses
+// steps 1..31 plus the lower half of step 32.  Tile pairs proven outside the cutoff by the
+// mask are skipped (all four row tiles out => the column tile is not even loaded).
+// grid = (ceil(NG / 4), offset chunks); the waves of a workgroup are independent.
+// ===========================================================================
+__device__ __forceinline__ double dpp_rotate(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <bool LANE_PRED>
+__device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
+                                        double xj, double yj, double zj,
+                                        double L, double invL, double rc2, bool lane_ok,
+                                        double &ax, double &ay, double &az,
+                                        double &jx, double &jy, double &jz,
+                                        double &s12, double &s6)
+{
+    const double dx = mic_fast(xi - xj, L, invL);
+    const double dy = mic_fast(yi - yj, L, invL);
+    const double dz = mic_fast(zi - zj, L, invL);
+    const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+    bool in = r2 < rc2;
+    if constexpr (LANE_PRED) in = in && lane_ok;
+    if (in) {
+        const double u = rcp_newton(r2);
         const double u3 = u * u * u;
         const double u6 = u3 * u3;
         s12 += u6;
@@ -89,70 +299,114 @@ __device__ __forceinline__ void pair_accum(double xi, double yi, double zi,
         ax = fma(g, dx, ax);
         ay = fma(g, dy, ay);
         az = fma(g, dz, az);
+        jx = fma(-g, dx, jx);
+        jy = fma(-g, dy, jy);
+        jz = fma(-g, dz, jz);
     }
 }
 
-// ---------------------------------------------------------------------------
-// K2 (v1): full-matrix gather.  grid = (row tiles, j chunks); one thread per row i.
-// The j coordinates are wave-uniform, so they are fetched with scalar loads and fed
-// to the VALU as SGPR operands -- no LDS staging, no per-lane address arithmetic.
-// pos = exchange buffer in shard-blocked SoA (ljmd.h); rows are the owned shard.
-// Output: slab[chunk][axis][row] raw partial accelerations, wg_part[wg][2] = s12,s6.
-// ---------------------------------------------------------------------------
-template <bool FAST_MIC>
-__global__ __launch_bounds__(kBlock) void pair_rows_kernel(PairArgs a)
+__global__ __launch_bounds__(kBlock, 4) void pair_n3_kernel(N3Args a)
 {
     __shared__ double red[2 * kWavesPerBlock];
-    const int row = blockIdx.x * kBlock + threadIdx.x;         // local row in the shard
-    const int gi = a.row0 + row;                               // global particle index
-    const bool live = row < a.rows;
-    const double *own = a.pos + (size_t)a.rank * 3 * a.shard;
-    const double nan = __builtin_nan("");
-    const double xi = live ? own[row] : nan;
-    const double yi = live ? own[a.shard + row] : nan;
-    const double zi = live ? own[2 * (size_t)a.shard + row] : nan;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int A = blockIdx.x * kWavesPerBlock + wave;          // row group, wave-uniform
+    const bool active = A < a.NG;
+    const size_t P = a.P;
 
-    double ax = 0.0, ay = 0.0, az = 0.0, s12 = 0.0, s6 = 0.0;
-
-    const int j0 = blockIdx.y * a.chunk;
-    const int j1 = min(j0 + a.chunk, a.n);
-    // rows of this block as a global index range, for the self-pair exclusion
-    const int blo = a.row0 + blockIdx.x * kBlock, bhi = blo + kBlock;
-
-    for (int j = j0; j < j1;) {
-        const int g = j / a.shard;                              // source shard block (uniform)
-        const int jl = j - g * a.shard;
-        const int jend_blk = min(j1, (g + 1) * a.shard);
-        const double *bx = a.pos + (size_t)g * 3 * a.shard;
-        const double *by = bx + a.shard, *bz = by + a.shard;
-        const int cnt = jend_blk - j;
-        // split at the block's own rows so that only that segment pays the j != i test
-        int k = 0;
-        while (k < cnt) {
-            const int jg = j + k;
-            if (jg >= blo && jg < bhi) {
-                const int stop = min(cnt, bhi - j);
-                for (; k < stop; ++k) {
-                    if (j + k != gi)
-                        pair_accum<FAST_MIC>(xi, yi, zi, bx[jl + k], by[jl + k], bz[jl + k],
-                                             a.L, a.invL, a.rc2, ax, ay, az, s12, s6);
-                }
-            } else {
-                const int stop = (jg < blo) ? min(cnt, blo - j) : cnt;
-#pragma unroll 4
-                for (; k < stop; ++k)
-                    pair_accum<FAST_MIC>(xi, yi, zi, bx[jl + k], by[jl + k], bz[jl + k],
-                                         a.L, a.invL, a.rc2, ax, ay, az, s12, s6);
-            }
-        }
-        j = jend_blk;
+    double xi[kRowTiles], yi[kRowTiles], zi[kRowTiles];
+    double ax[kRowTiles], ay[kRowTiles], az[kRowTiles];
+    double s12 = 0.0, s6 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kRowTiles; ++k) {
+        const size_t slot = (size_t)(active ? kRowTiles * A + k : 0) * kTile + lane;
+        xi[k] = a.pos[slot];
+        yi[k] = a.pos[P + slot];
+        zi[k] = a.pos[2 * P + slot];
+        ax[k] = ay[k] = az[k] = 0.0;
     }
 
-    if (live) {
-        double *s = a.slab + (size_t)blockIdx.y * 3 * a.shard;
-        s[row] = ax;
-        s[a.shard + row] = ay;
-        s[2 * (size_t)a.shard + row] = az;
+    const int d0 = blockIdx.y * a.dchunk;
+    const int d1 = active ? min(d0 + a.dchunk, a.Dmax + 1) : d0;
+    for (int d = d0; d < d1; ++d) {
+        int B = A + d;
+        if (B >= a.NG) B -= a.NG;
+        const bool own = (d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B);
+        for (int l = 0; l < kRowTiles; ++l) {
+            const int c = kRowTiles * B + l;                   // column tile
+            const size_t blk = (size_t)A * a.Q + (size_t)d * kRowTiles + l;
+            unsigned mb = 0;
+            if (own) {
+#pragma unroll
+                for (int k = 0; k < kRowTiles; ++k) {
+                    const uint64_t w = a.mask[(size_t)(kRowTiles * A + k) * a.W + (c >> 6)];
+                    mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
+                }
+                if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
+            }
+            if (mb == 0) {
+                if (lane == 0) a.flag_j[blk] = 0;
+                continue;
+            }
+            const size_t cs = (size_t)c * kTile + lane;
+            double xj = a.pos[cs], yj = a.pos[P + cs], zj = a.pos[2 * P + cs];
+            double jx = 0.0, jy = 0.0, jz = 0.0;
+
+            if (d == 0 && ((mb >> l) & 1u)) {
+                // the column tile is one of the wave's own row tiles: tile l against itself
+                for (int s = 0; s < kTile; ++s) {
+#pragma unroll
+                    for (int k = 0; k < kRowTiles; ++k) {
+                        if (!((mb >> k) & 1u)) continue;
+                        if (k == l) {
+                            if (s >= 1 && s <= 32)
+                                pair_n3<true>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2,
+                                              s < 32 || lane < 32, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+                        } else {
+                            pair_n3<false>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true,
+                                           ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+                        }
+                    }
+                    xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
+                    jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
+                }
+            } else if (mb == 15u) {
+                for (int s = 0; s < kTile; ++s) {
+#pragma unroll
+                    for (int k = 0; k < kRowTiles; ++k)
+                        pair_n3<false>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true,
+                                       ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+                    xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
+                    jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
+                }
+            } else {
+                for (int s = 0; s < kTile; ++s) {
+#pragma unroll
+                    for (int k = 0; k < kRowTiles; ++k)
+                        if ((mb >> k) & 1u)
+                            pair_n3<false>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true,
+                                           ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+                    xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
+                    jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
+                }
+            }
+            double *o = a.slab_j + blk * (3 * kTile) + lane;
+            o[0] = jx;
+            o[kTile] = jy;
+            o[2 * kTile] = jz;
+            if (lane == 0) a.flag_j[blk] = 1;
+        }
+    }
+
+    if (active) {
+        double *si = a.slab_i + (size_t)blockIdx.y * 3 * P;
+#pragma unroll
+        for (int k = 0; k < kRowTiles; ++k) {
+            const size_t slot = (size_t)(kRowTiles * A + k) * kTile + lane;
+            si[slot] = ax[k];
+            si[P + slot] = ay[k];
+            si[2 * P + slot] = az[k];
+        }
     }
     double v[2] = {s12, s6};
     block_sum<2>(v, red);
@@ -164,7 +418,71 @@ __global__ __launch_bounds__(kBlock) void pair_rows_kernel(PairArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// K1: drift + wrap + first half-kick + unwrapped update, one thread per particle.
+// Geometry pre-pass 1: exact axis-aligned bounding box of every 64-slot tile of the
+// exchange buffer (NaN padding ignored).  One wave per tile; reads 24 N bytes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void tile_boxes_kernel(GeometryArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (t >= a.T) return;
+    const int g = t / a.TB, tl = t - g * a.TB;
+    const double *b = a.pos + (size_t)g * 3 * a.P + (size_t)tl * kTile + lane;
+    const double x = b[0], y = b[a.P], z = b[2 * (size_t)a.P];
+    const double lx = wave_min(x), ly = wave_min(y), lz = wave_min(z);
+    const double hx = wave_max(x), hy = wave_max(y), hz = wave_max(z);
+    if (lane == 0) {
+        double *o = a.bbox + (size_t)t * kBoxStride;
+        o[0] = lx; o[1] = ly; o[2] = lz;
+        o[3] = hx; o[4] = hy; o[5] = hz;
+    }
+}
+
+// Lower bound of |d - m L| over d in [lo, hi], m integer, |d| < 2.5 L.
+__device__ __forceinline__ double axis_gap(double lo, double hi, double L)
+{
+    double g = __builtin_inf();
+#pragma unroll
+    for (int m = -2; m <= 2; ++m) {
+        const double c = m * L;
+        if (lo <= c && c <= hi) return 0.0;
+        g = fmin(g, fmin(fabs(lo - c), fabs(hi - c)));
+    }
+    return g;
+}
+
+// ---------------------------------------------------------------------------
+// Geometry pre-pass 2: tile-pair mask.  Bit J of row I is cleared only when the boxes
+// prove that every pair (i in I, j in J) has r^2 > rc^2 (1 + 1e-10) under the minimum
+// image -- such pairs fail the reference's `rij2 < rc_square` test, so skipping them
+// changes nothing.  One wave per (row tile, 64-column word); lane = column tile.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int Il = blockIdx.y * kWavesPerBlock + (threadIdx.x >> 6);
+    const int w = blockIdx.x;
+    if (Il >= a.TB) return;
+    const int I = a.rank * a.TB + Il;
+    const int J = w * 64 + lane;
+    bool keep = false;
+    if (J < a.T) {
+        const double *bi = a.bbox + (size_t)I * kBoxStride;
+        const double *bj = a.bbox + (size_t)J * kBoxStride;
+        double d2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double g = axis_gap(bi[k] - bj[3 + k], bi[3 + k] - bj[k], a.L);
+            d2 += g * g;
+        }
+        keep = !(d2 > a.rc2_skin) || (J == I);
+    }
+    const uint64_t word = __ballot(keep);
+    if (lane == 0) a.mask[(size_t)Il * a.W + w] = word;
+}
+
+// ---------------------------------------------------------------------------
+// K1: drift + wrap + first half-kick + unwrapped update, one thread per slot.
 //   r  = (r + v*dt) + a*dt_square_half        verlet.f90:58-60   (left-to-right, unfused)
 //   r  = r - L*floor(r*invL)                  geometry_pbc.f90:54-56
 //   v  = v + a*dt_half                        verlet.f90:72-74
@@ -177,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
     if (i >= a.rows) return;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
-        const size_t o = (size_t)ax * a.shard + i;
+        const size_t o = (size_t)ax * a.P + i;
         const double r0 = a.r[o], v0 = a.v[o], acc = a.a[o];
         double r1 = (r0 + v0 * a.dt) + acc * a.dt_sq_half;
         r1 = r1 - a.L * __builtin_floor(r1 * a.invL);
@@ -190,24 +508,46 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// K3: reduce the partial-acceleration slabs in fixed chunk order, restore the x24
-// prefactor (lj_potential_energy.f90:189-191), optionally apply the second half-kick
+// K3: reduce the partial-acceleration slabs (row side, and for Newton-3 also the column-side
+// blocks addressed to this tile) in fixed order, restore the x24 prefactor
+// (lj_potential_energy.f90:189-191), optionally apply the second half-kick
 // (verlet.f90:86-88) and emit per-block partial sums of vx^2, vy^2, vz^2
 // (verlet.f90:93-95 keeps the three sums separate).
 // ---------------------------------------------------------------------------
-template <bool KICK>
+template <bool KICK, bool N3>
 __global__ __launch_bounds__(kBlock) void reduce_kick_kernel(IntegrateArgs a)
 {
     __shared__ double red[3 * kWavesPerBlock];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     double k2[3] = {0.0, 0.0, 0.0};
     if (i < a.rows) {
+        double s[3];
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            const size_t o = (size_t)ax * a.shard + i;
-            double s = a.slab[o];
-            for (int c = 1; c < a.nslab; ++c) s += a.slab[(size_t)c * 3 * a.shard + o];
-            const double acc = 24.0 * s;
+            const size_t o = (size_t)ax * a.P + i;
+            s[ax] = a.slab[o];
+            for (int c = 1; c < a.nslab; ++c) s[ax] += a.slab[(size_t)c * 3 * a.P + o];
+        }
+        if constexpr (N3) {
+            // column-side blocks of this particle's tile, in fixed offset order d = 0 .. Dmax
+            const int c = i / kTile, lane = i - c * kTile;
+            const int B = c / kRowTiles, l = c - B * kRowTiles;
+            for (int d = 0; d <= a.Dmax; ++d) {
+                int A = B - d;
+                if (A < 0) A += a.NG;
+                const size_t blk = (size_t)A * a.Q + (size_t)d * kRowTiles + l;
+                if (a.flag_j[blk]) {
+                    const double *b = a.slab_j + blk * (3 * kTile) + lane;
+                    s[0] += b[0];
+                    s[1] += b[kTile];
+                    s[2] += b[2 * kTile];
+                }
+            }
+        }
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const size_t o = (size_t)ax * a.P + i;
+            const double acc = 24.0 * s[ax];
             a.a[o] = acc;
             if constexpr (KICK) {
                 const double v1 = a.v[o] + acc * a.dt_half;
@@ -235,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void kinetic_fused_kernel(IntegrateArgs a)
     const int i = blockIdx.x * kBlock + threadIdx.x;
     double k[1] = {0.0};
     if (i < a.rows) {
-        const double vx = a.v[i], vy = a.v[a.shard + i], vz = a.v[2 * (size_t)a.shard + i];
+        const double vx = a.v[i], vy = a.v[a.P + i], vz = a.v[2 * (size_t)a.P + i];
         k[0] = vx * vx + vy * vy + vz * vz;
     }
     block_sum<1>(k, red);
@@ -271,8 +611,8 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinalizeArgs a)
     if (threadIdx.x == 0) {
         const unsigned pos = *a.ring_pos;
         double *rec = a.ring + (size_t)(pos % a.ring_cap) * kPartialStride;
-        rec[0] = v[0];
-        rec[1] = v[1];
+        rec[0] = v[0] * a.pair_scale;   // exact: the scale is 0.5 or 1
+        rec[1] = v[1] * a.pair_scale;
         rec[2] = v[2];
         rec[3] = v[3];
         rec[4] = v[4];
@@ -286,12 +626,33 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinalizeArgs a)
 // ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
-hipError_t launch_pair_rows(const PairArgs &a, bool fast_mic, dim3 grid, hipStream_t s)
+hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s)
 {
-    if (fast_mic)
-        hipLaunchKernelGGL(pair_rows_kernel<true>, grid, dim3(kBlock), 0, s, a);
-    else
-        hipLaunchKernelGGL(pair_rows_kernel<false>, grid, dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(pair_rows_generic_kernel, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(pair_tiles_kernel, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(pair_n3_kernel, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(tile_boxes_kernel, dim3((a.T + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(tile_mask_kernel, dim3(a.W, (a.TB + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
@@ -304,10 +665,15 @@ hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s)
 hipError_t launch_reduce_kick(const IntegrateArgs &a, bool kick, hipStream_t s)
 {
     const dim3 grid((a.rows + kBlock - 1) / kBlock);
-    if (kick)
-        hipLaunchKernelGGL(reduce_kick_kernel<true>, grid, dim3(kBlock), 0, s, a);
+    const bool n3 = a.slab_j != nullptr;
+    if (kick && n3)
+        hipLaunchKernelGGL((reduce_kick_kernel<true, true>), grid, dim3(kBlock), 0, s, a);
+    else if (kick)
+        hipLaunchKernelGGL((reduce_kick_kernel<true, false>), grid, dim3(kBlock), 0, s, a);
+    else if (n3)
+        hipLaunchKernelGGL((reduce_kick_kernel<false, true>), grid, dim3(kBlock), 0, s, a);
     else
-        hipLaunchKernelGGL(reduce_kick_kernel<false>, grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL((reduce_kick_kernel<false, false>), grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

@@ -90,6 +90,7 @@ class ShardedSimulation:
         """Every rank passes the same global r[3, N], v[3, N] (md_simulation_program.f90:221-236).
         -> (epot, d_epot, dd_epot) of the t = 0 force evaluation."""
         self.engine.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        self.exchange_positions()      # every rank re-orders its own block at set_state: share the new order
         self.engine.forces_partial()
         parts = self._gather_partials(self.engine.read_partials(1))
         e, _k, d, dd = self._combine(parts)

@@ -213,10 +213,13 @@ class Engine:
     def profile_enable(self, on: bool = True) -> None:
         self._ck(self._lib.ljmd_profile_enable(self._h, 1 if on else 0))
 
-    def profile_read(self):
-        f, g, c = C.c_double(), C.c_double(), C.c_int32()
-        self._ck(self._lib.ljmd_profile_read(self._h, C.byref(f), C.byref(g), C.byref(c)))
-        return f.value, g.value, c.value
+    def profile_read(self) -> dict:
+        """-> {'pair_ms', 'geometry_ms', 'drift_ms', 'reduce_ms', 'launches'} averages per launch"""
+        ms = (C.c_double * 4)()
+        c = C.c_int32()
+        self._ck(self._lib.ljmd_profile_read(self._h, ms, C.byref(c)))
+        return {"pair_ms": ms[0], "geometry_ms": ms[1], "drift_ms": ms[2], "reduce_ms": ms[3],
+                "launches": c.value}
 
 
 def observables(params: SimParams, epot: float, ekin: float, d_epot: float):

@@ -50,6 +50,39 @@ def test_force_call_vs_reference_golden(golden, name):
     check_force(sc, a, g)
 
 
+@pytest.mark.parametrize("name", ["force_n108", "force_n500", "force_n4000", "force_n4096"])
+def test_newton3_kernel_vs_reference_golden(golden, name, monkeypatch):
+    """The Newton-3 rotation kernel normally engages at N >= 16384; force it at the golden sizes.
+    N=108 -> one row group (diagonal only), N=500 -> two groups (the d = NG/2 tie rule),
+    N=4000/4096 -> 16 groups, 9 offsets."""
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+    g = golden(name)
+    n = int(g["n"])
+    p = init_params(n, float(g["L"]), 0.005, float(g["rc"]))
+    r = g["r"]
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], r[0], r[1], r[2])
+        sc = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+        sc2 = eng.compute_forces()                      # second call: slab flags must be rewritten
+        a2 = np.stack(eng.get_state(("a",))["a"])
+    check_force(sc, a, g)
+    assert sc == sc2 and np.array_equal(a, a2)
+
+
+def test_newton3_short_trajectory(golden, monkeypatch):
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+    g = golden("traj_n4096_200")
+    p = init_params(4096, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    ref = g["scalars"][:201]
+    with Engine(p) as eng:
+        s0 = _start(eng, g)
+        e, k, d, dd = eng.verlet_steps(200)
+    mine = np.vstack([s0, np.stack([e, k, d, dd], axis=1)])
+    for nm, a, b in zip(("etot", "T", "P"), _series(p, mine), _series(p, ref)):
+        assert np.max(np.abs(a - b) / np.abs(b)) <= REL_TRAJ, nm
+
+
 def test_force_fcc108_known_answer(golden, oracle):
     g = golden("force_fcc108")
     L = float(g["L"])
@@ -238,6 +271,58 @@ def test_large_n_properties_262144():
         gfac = (2.0 * u3 * u3 - u3) * u
         a_np = 24.0 * (gfac * dvec[:, m]).sum(axis=1)
         assert np.abs(a_np - a1[:, i]).max() < 1e-10 * max(np.abs(a_np).max(), 1.0)
+
+
+def test_fast_path_equals_generic_path(golden, monkeypatch):
+    """The sorted / tile-skipping / rcp+Newton fast path against the exact generic kernel
+    (dnint minimum image, IEEE divide, no sorting, no skipping) on the same device."""
+    g = golden("traj_n4096_200")
+    p = init_params(4096, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    res = {}
+    for mode in ("fast", "generic", "nosort"):
+        if mode == "generic":
+            monkeypatch.setenv("LJMD_FORCE_GENERIC", "1")
+        elif mode == "nosort":
+            monkeypatch.setenv("LJMD_SORT", "0")
+        with Engine(p) as eng:
+            s0 = _start(eng, g)
+            sc = np.stack(eng.verlet_steps(25), axis=1)
+            st = eng.get_state()
+        monkeypatch.delenv("LJMD_FORCE_GENERIC", raising=False)
+        monkeypatch.delenv("LJMD_SORT", raising=False)
+        res[mode] = (np.array(s0), sc, np.concatenate([np.stack(st[k]) for k in ("r", "ru", "v", "a")]))
+    for mode in ("generic", "nosort"):
+        assert np.max(np.abs(res["fast"][0] - res[mode][0]) / np.abs(res[mode][0])) < 1e-13
+        assert np.max(np.abs(res["fast"][1] - res[mode][1]) / np.abs(res[mode][1])) < 1e-11
+        assert np.max(np.abs(res["fast"][2] - res[mode][2])) < 1e-9
+
+
+def test_resort_keeps_particle_identity(golden):
+    """Re-sorting happens inside verlet_steps; get_state must still return original order, and
+    set_accel / set_unwrapped must land on the right particles after a sort."""
+    g = golden("traj_n4096_200")
+    n = 4096
+    p = init_params(n, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    r0, v0 = g["r0"], g["v0"]
+    with Engine(p) as eng:
+        eng.set_state(r0[0], r0[1], r0[2], v0[0], v0[1], v0[2])
+        st = eng.get_state(("r", "v", "ru"))
+        assert np.array_equal(np.stack(st["r"]), r0) and np.array_equal(np.stack(st["v"]), v0)
+        assert np.array_equal(np.stack(st["ru"]), r0)
+        tag = np.arange(n, dtype=np.float64)
+        eng.set_accel(tag, tag + 0.25, tag + 0.5)
+        eng.set_unwrapped(-tag, tag * 2, tag * 3)
+        st = eng.get_state(("a", "ru"))
+        assert np.array_equal(st["a"][0], tag) and np.array_equal(st["a"][2], tag + 0.5)
+        assert np.array_equal(st["ru"][1], tag * 2)
+        eng.set_unwrapped(r0[0], r0[1], r0[2])
+        eng.compute_forces()
+        eng.verlet_steps(35)                      # crosses three re-sorts (every 10 steps)
+        fin = eng.get_state(("r", "ru"))
+    # unwrapped - wrapped must be an integer number of box lengths for the SAME particle
+    k = (np.stack(fin["ru"]) - np.stack(fin["r"])) / p.box_length
+    assert np.max(np.abs(k - np.round(k))) < 1e-9
+    assert np.max(np.abs(np.stack(fin["ru"]) - r0)) < 1.0    # nobody moved a sigma in 35 steps
 
 
 def test_argument_guards_and_sequence_errors():
