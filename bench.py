@@ -9,7 +9,8 @@
 One "step" = one full MD step on synthetic input already resident in HBM: drift + wrap +
 half-kick + unwrapped update, all-pairs LJ forces/energy/virial, second half-kick, kinetic
 energy.  For N > 1 the SAME 262 144-particle system is sharded by particle rows (strong
-scaling) with one RCCL all-gather of positions per step.  Rank 0 prints ONE JSON line.
+scaling) with one RCCL all-gather of positions per step (issued inside libljmd.so; torch.distributed/gloo is the
+control plane: RCCL-id bootstrap, barrier, scalar gather).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -74,31 +75,35 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     import torch
-    import ljmd_amd
+    # torch ships its own ROCm runtime next to the system one libljmd.so links: initialise torch's
+    # first (the order that is known to work), use it only for the contract's synchronize calls
+    torch_gpu = torch.cuda.is_available()
+    if torch_gpu:
+        torch.cuda.set_device(local_rank)
+    import ljmd_amd  # noqa: F401
     from ljmd_amd import Engine, synthetic, distributed
 
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        # control plane only (RCCL-id broadcast, barrier, partial-record gather): CPU tensors over gloo;
+        # the position all-gather is RCCL over xGMI, issued inside libljmd.so on the engine's stream
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n = args.n
     p, r, v = synthetic.make_config(n)
     eng = Engine(p, device=local_rank, rank=rank, n_ranks=world)
-    if world > 1:
-        full, own = distributed.hip_exchange_tensors(eng, local_rank)
-        sim = distributed.ShardedSimulation(eng, full, own, rank, world,
-                                            stream_context=distributed.hip_stream_context(eng, local_rank))
-    else:
-        sim = distributed.ShardedSimulation(eng, None, None, 0, 1)
+    distributed.bootstrap_rccl(eng, rank, world)
+    sim = distributed.ShardedSimulation(eng, rank, world)
 
     def barrier():
+        eng.synchronize()                    # hipStreamSynchronize + hipDeviceSynchronize on the engine's device
+        if torch_gpu:
+            torch.cuda.synchronize(local_rank)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(local_rank)
+            eng.synchronize()
 
     e0, d0, dd0 = sim.start(r, v)
     if args.warmup > 0:
@@ -116,7 +121,7 @@ def main() -> None:
     epot, ekin, d_epot, dd_epot = sim.collect(args.steps)
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -157,6 +157,21 @@ void *ljmd_exchange_buffer(ljmd_t *h, int64_t *n_doubles_total, int64_t *own_off
 /* Device address of one resident state array (LJMD_R..LJMD_A, axis 0..2), P slots in
  * the current device slot order; for zero-copy views (e.g. torch via __cuda_array_interface__). */
 void *ljmd_device_ptr(ljmd_t *h, int32_t which, int32_t axis);
+/*
+ * RCCL exchange over xGMI.  Rank 0 obtains an id (ncclGetUniqueId) and ships the
+ * LJMD_COMM_ID_BYTES to every rank by any out-of-band channel (bench.py: a gloo
+ * broadcast); every rank then calls ljmd_comm_init, which joins the communicator with the
+ * rank / n_ranks given to ljmd_create.  ljmd_allgather_positions enqueues ONE in-place
+ * ncclAllGather of 3*P doubles per rank on the handle's stream -- ordered behind
+ * ljmd_step_begin's kernels and ahead of ljmd_step_finish's, no host synchronisation.
+ * With n_ranks = 1 it is a no-op and needs no communicator.
+ */
+#define LJMD_COMM_ID_BYTES 128
+int ljmd_comm_unique_id(char *id_out /* [LJMD_COMM_ID_BYTES] */);
+int ljmd_comm_init(ljmd_t *h, const char *id /* [LJMD_COMM_ID_BYTES] */);
+int ljmd_allgather_positions(ljmd_t *h);
+/* Blocks the host until everything enqueued on the handle's stream (and device) is done. */
+int ljmd_synchronize(ljmd_t *h);
 /* The HIP stream (hipStream_t) all of this handle's kernels are launched on. */
 void *ljmd_stream(ljmd_t *h);
 /* Phase 1: drift + wrap + half-kick + unwrapped update of the owned shard; the new

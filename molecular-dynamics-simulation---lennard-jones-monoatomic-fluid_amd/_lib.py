@@ -26,6 +26,7 @@ PRECISION_FP32_FORCE = 1
 
 R, RU, V, A = 0, 1, 2, 3
 PARTIAL_STRIDE = 8
+COMM_ID_BYTES = 128
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -62,6 +63,10 @@ PROTOTYPES = {
     "ljmd_exchange_buffer": (C.c_void_p, [C.c_void_p, c_int64_p, c_int64_p, c_int64_p]),
     "ljmd_device_ptr": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32]),
     "ljmd_stream": (C.c_void_p, [C.c_void_p]),
+    "ljmd_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "ljmd_comm_init": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "ljmd_allgather_positions": (C.c_int, [C.c_void_p]),
+    "ljmd_synchronize": (C.c_int, [C.c_void_p]),
     "ljmd_step_begin": (C.c_int, [C.c_void_p]),
     "ljmd_step_finish": (C.c_int, [C.c_void_p]),
     "ljmd_forces_partial": (C.c_int, [C.c_void_p]),

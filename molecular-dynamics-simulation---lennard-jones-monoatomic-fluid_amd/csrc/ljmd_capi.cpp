@@ -7,6 +7,7 @@
 #include "ljmd.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -60,6 +61,7 @@ struct ljmd {
     int resort_every = 10, steps_since_sort = 0, ncell = 1;
 
     hipStream_t stream = nullptr;
+    ncclComm_t comm = nullptr;        // RCCL communicator over the G ranks (multi-GPU only)
     // ---- HBM-resident state (layout: ljmd_internal.h) ----
     double *d_pos = nullptr;      // [G][3][P] exchange buffer (all positions)
     double *d_ru = nullptr, *d_v = nullptr, *d_a = nullptr;   // [3][P]
@@ -376,6 +378,7 @@ void release(ljmd_t *h)
     if (!h) return;
     if (h->device >= 0) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) (void)ncclCommDestroy(h->comm);
     for (auto &q : h->ev_pool)
         for (auto &e : q.e) (void)hipEventDestroy(e);
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
@@ -817,6 +820,57 @@ int ljmd_combine_scalars(const ljmd_t *h, const double *partials_by_rank, int32_
     if (!h || !partials_by_rank || n_ranks < 1)
         return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_combine_scalars: bad argument");
     combine_one(h, partials_by_rank, n_ranks, epot, ekin, d_epot, dd_epot);
+    return LJMD_OK;
+}
+
+// ---- RCCL exchange (one process per GPU) -------------------------------------
+
+int ljmd_comm_unique_id(char *id_out)
+{
+    if (!id_out) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_comm_unique_id: NULL buffer");
+    static_assert(sizeof(ncclUniqueId) == LJMD_COMM_ID_BYTES, "LJMD_COMM_ID_BYTES out of sync with RCCL");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, LJMD_ERR_HIP, "ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+    std::memcpy(id_out, id.internal, sizeof id.internal);
+    return LJMD_OK;
+}
+
+int ljmd_comm_init(ljmd_t *h, const char *id)
+{
+    if (!h || !id) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_comm_init: NULL argument");
+    if (h->comm) return fail(h, LJMD_ERR_STATE, "ljmd_comm_init: communicator already initialised");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    ncclUniqueId uid;
+    std::memcpy(uid.internal, id, sizeof uid.internal);
+    const ncclResult_t r = ncclCommInitRank(&h->comm, h->G, uid, h->rank);
+    if (r != ncclSuccess) {
+        h->comm = nullptr;
+        return fail(h, LJMD_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", h->rank, h->G, ncclGetErrorString(r));
+    }
+    return LJMD_OK;
+}
+
+int ljmd_allgather_positions(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_allgather_positions: NULL handle");
+    if (h->G == 1) return LJMD_OK;
+    if (!h->comm) return fail(h, LJMD_ERR_STATE, "ljmd_allgather_positions: call ljmd_comm_init first");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    // in place: the send block is this rank's slice of the receive buffer; enqueued on the engine's
+    // stream, i.e. behind the drift/kick (and re-sort) kernels and ahead of the pair kernel
+    const size_t count = 3 * (size_t)h->P;
+    const ncclResult_t r = ncclAllGather(own_block(h), h->d_pos, count, ncclDouble, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+    return LJMD_OK;
+}
+
+int ljmd_synchronize(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_synchronize: NULL handle");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    LJMD_HIP(h, hipDeviceSynchronize());
     return LJMD_OK;
 }
 

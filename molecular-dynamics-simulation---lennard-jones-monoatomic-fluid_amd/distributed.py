@@ -1,79 +1,62 @@
-"""Multi-GPU run of the hot path: one process per GPU, `torch.distributed` (backend "nccl" =
-RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""Multi-GPU run of the hot path: one process per GPU, launched by torch.distributed.run.
 
-Sharding: rank g integrates the contiguous particle range
-[g*S, (g+1)*S), S = N / G, and evaluates those rows of the pair matrix against ALL N
-positions.  Per MD step there is exactly one data-path exchange: an in-place all-gather
-of the freshly drifted position shard (3*S doubles per rank) into the shard-blocked
-exchange buffer, issued on the engine's own HIP stream right after the drift/half-kick
-kernel, so that it is ordered behind it and ahead of the pair kernel without any host
-synchronisation.  The per-step scalar partial sums (S12, S6, Kx, Ky, Kz per rank) stay on
-the device; they are gathered once per `run()` call and combined on the host in fixed rank
-order, so the result does not depend on collective internals.
+Sharding: rank g integrates the contiguous particle range [g*S, (g+1)*S),
+S = N / G, and evaluates those rows of the pair matrix against ALL N positions.
 
-The engine object is injected: the product uses `ljmd_amd.Engine` (HIP); the CPU tests
-inject an oracle-backed stand-in to exercise this file's sharding/exchange logic with gloo.
+Data path -- exactly one exchange per MD step: an in-place RCCL all-gather (over xGMI) of the
+freshly drifted position block, 3*P doubles per rank, issued by the engine itself
+(`ljmd_allgather_positions`) on its own HIP stream: behind the drift/half-kick kernel, ahead of
+the pair kernel, no host synchronisation.  The library talks to RCCL directly; its communicator
+is bootstrapped here by shipping rank 0's 128-byte RCCL unique id through the
+`torch.distributed` process group (`bootstrap_rccl`).
+
+Control plane -- `torch.distributed` (backend gloo: CPU tensors only): the unique-id broadcast,
+barriers, and ONE gather per `run()` of the per-step partial records (S12, S6, Kx, Ky, Kz per
+rank), which are then combined on the host in fixed rank order, so the scalars do not depend on
+collective internals and every rank computes bit-identical values.
+
+The engine object is injected: the product uses `ljmd_amd.Engine` (HIP); the CPU tests inject an
+oracle-backed stand-in to exercise this file's logic with world_size 2 over gloo.
 """
 from __future__ import annotations
-
-import contextlib
 
 import numpy as np
 
 PARTIAL_STRIDE = 8
 
 
-class _DeviceArray:
-    """Zero-copy view of library-owned HBM for torch (via __cuda_array_interface__)."""
-
-    def __init__(self, ptr: int, count: int):
-        self.__cuda_array_interface__ = {
-            "shape": (count,), "typestr": "<f8", "data": (int(ptr), False), "version": 3, "strides": None}
-
-
-def hip_exchange_tensors(engine, device_index: int):
-    """-> (full exchange buffer as a 1-D torch tensor on the GPU, view of this rank's block)."""
-    import torch
-    ptr, total, off, cnt = engine.exchange_buffer()
-    full = torch.as_tensor(_DeviceArray(ptr, total), device=torch.device("cuda", device_index))
-    return full, full[off:off + cnt]
-
-
-def hip_stream_context(engine, device_index: int):
-    """Makes the engine's HIP stream torch's current stream so collectives are ordered on it."""
-    import torch
-    ext = torch.cuda.ExternalStream(engine.stream(), device=torch.device("cuda", device_index))
-    return lambda: torch.cuda.stream(ext)
+def bootstrap_rccl(engine, rank: int, world: int, group=None) -> None:
+    """Creates the engine's RCCL communicator: rank 0 draws the unique id, everybody joins."""
+    if world == 1:
+        return
+    import torch.distributed as dist
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(box[0])
 
 
 class ShardedSimulation:
-    def __init__(self, engine, full_tensor, own_view, rank: int, world: int, group=None,
-                 stream_context=None):
-        import torch.distributed as dist
-        self.dist = dist
+    def __init__(self, engine, rank: int, world: int, group=None):
         self.engine = engine
-        self.full, self.own = full_tensor, own_view
         self.rank, self.world, self.group = rank, world, group
-        self.stream_context = stream_context or contextlib.nullcontext
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
 
     # -- the one data-path collective ---------------------------------------------
     def exchange_positions(self) -> None:
-        if self.world == 1:
-            return
-        with self.stream_context():
-            self.dist.all_gather_into_tensor(self.full, self.own, group=self.group)
+        if self.world > 1:
+            self.engine.allgather_positions()
 
     def _gather_partials(self, mine: np.ndarray) -> np.ndarray:
         """mine: [k, PARTIAL_STRIDE] -> [world, k, PARTIAL_STRIDE] (host, tiny)."""
-        import torch
         if self.world == 1:
             return mine[None]
-        t = torch.from_numpy(np.ascontiguousarray(mine))
-        if self.dist.get_backend(self.group) == "nccl":
-            t = t.to(self.full.device)
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(mine)).reshape(-1)
+        out = torch.empty(self.world * t.numel(), dtype=t.dtype)
         self.dist.all_gather_into_tensor(out, t, group=self.group)
-        return out.cpu().numpy()
+        return out.numpy().reshape((self.world,) + tuple(mine.shape))
 
     def _combine(self, parts: np.ndarray):
         """parts [world, k, stride] -> four arrays of length k, ranks added in rank order."""

@@ -1,0 +1,131 @@
+!==============================================================================
+! md_simulation_gpu -- thin Fortran driver of the MI355X engine.
+!
+! Same inputs and outputs as the reference's production program for the part that touches
+! the hot path (scripts/md_simulation_program.f90:208-391):
+!   in : inputs/input_simulation_parameters.txt, outputs/rv_init.dat
+!   out: outputs/one_run/instantaneous_energies.dat   header :294, rows :374
+!        outputs/one_run/rva.dat                      header :254-257, records :384-387
+! Differences: the state lives in HBM for the whole run (ljmd_verlet_steps advances up to the
+! next sampling step without touching the host; r, ru, v, a come back only when a snapshot is
+! written), the per-step unwrapped-coordinate update (:339-353) happens inside the drift
+! kernel, and the statistics / correlation post-processing (:401-560) is not part of this
+! driver.  Environment: LJMD_DEVICE (default 0).
+!==============================================================================
+program md_simulation_gpu
+  use, intrinsic :: iso_c_binding
+  use define_precision, only: dp_kind, int_kind
+  use md_types,         only: sim_params, sim_state, init_state
+  use read_input_files, only: read_simulation_parameters
+  use ljmd_c_api
+  implicit none
+
+  type(sim_params) :: params
+  type(sim_state), target :: state
+  real(kind=dp_kind), allocatable, target :: rux(:), ruy(:), ruz(:)
+  real(kind=dp_kind), allocatable, target :: s_epot(:), s_ekin(:), s_depot(:), s_ddepot(:)
+  integer(kind=int_kind) :: total_steps, output_interval, warmup_steps, n_snapshots_expected
+  real(kind=dp_kind) :: rc_over_L, target_total_energy
+  real(kind=dp_kind) :: epot, ekin, etot, d_epot, dd_epot, time, temp_inst, press_inst, npd, rho
+  integer(kind=int_kind) :: step, next_sample, count, k, num_samples
+  integer :: iu_rva, iu_out, ios, device
+  integer(kind=8) :: c0, c1, crate
+  type(c_ptr) :: engine
+  character(len=32) :: env
+
+  call read_simulation_parameters('inputs/input_simulation_parameters.txt', params, total_steps, &
+                                  output_interval, warmup_steps, rc_over_L, target_total_energy)
+  call init_state(params, state)
+  call read_rv_init('outputs/rv_init.dat')
+  allocate(rux(params%n), ruy(params%n), ruz(params%n))
+
+  device = 0
+  call get_environment_variable('LJMD_DEVICE', env, status=ios)
+  if (ios == 0 .and. len_trim(env) > 0) read(env, *) device
+
+  call ljmd_check(ljmd_create(engine, params%n, params%box_length, params%dt, params%rc, &
+                              LJMD_PRECISION_FP64, int(device, c_int32_t), 0_c_int32_t, 1_c_int32_t), &
+                  c_null_ptr, 'ljmd_create')
+  ! H2D; the library sets ru <- r (md_simulation_program.f90:229-231)
+  call ljmd_check(ljmd_set_state(engine, c_loc(state%rx), c_loc(state%ry), c_loc(state%rz), &
+                                 c_loc(state%vx), c_loc(state%vy), c_loc(state%vz)), engine, 'ljmd_set_state')
+  ! t = 0 forces and energies (:236-243)
+  call ljmd_check(ljmd_compute_forces(engine, epot, d_epot, dd_epot), engine, 'ljmd_compute_forces')
+  call ljmd_check(ljmd_kinetic_energy(engine, ekin), engine, 'ljmd_kinetic_energy')
+  etot = epot + ekin
+  time = 0.d0
+
+  open(newunit=iu_rva, file='outputs/one_run/rva.dat', form='unformatted', status='replace', &
+       action='write', iostat=ios)
+  if (ios /= 0) stop 'md_simulation: cannot open outputs/one_run/rva.dat'
+  n_snapshots_expected = (total_steps / output_interval) - (warmup_steps / output_interval)
+  if (n_snapshots_expected < 0) n_snapshots_expected = 0
+  write(iu_rva) params%n, params%box_length, params%dt, output_interval, n_snapshots_expected
+
+  open(newunit=iu_out, file='outputs/one_run/instantaneous_energies.dat', status='replace', &
+       action='write', iostat=ios)
+  if (ios /= 0) stop 'md_simulation: cannot open outputs/one_run/instantaneous_energies.dat'
+  write(iu_out, '(a)') '# time   epot   ekin   etot   T   P'
+
+  allocate(s_epot(output_interval + warmup_steps + 1), s_ekin(output_interval + warmup_steps + 1), &
+           s_depot(output_interval + warmup_steps + 1), s_ddepot(output_interval + warmup_steps + 1))
+  npd = dble(params%n)
+  rho = npd / params%volume
+  num_samples = 0
+  step = 0
+  call system_clock(c0, crate)
+  do while (step < total_steps)
+    ! first step > `step` that satisfies the sampling condition of :361
+    next_sample = (step / output_interval + 1) * output_interval
+    do while (next_sample <= warmup_steps)
+      next_sample = next_sample + output_interval
+    end do
+    next_sample = min(next_sample, total_steps)
+    count = next_sample - step
+    call ljmd_check(ljmd_verlet_steps(engine, count, c_loc(s_epot), c_loc(s_ekin), c_loc(s_depot), &
+                                      c_loc(s_ddepot)), engine, 'ljmd_verlet_steps')
+    do k = 1, count
+      time = time + params%dt                       ! accumulated as at :356
+    end do
+    step = next_sample
+    epot = s_epot(count); ekin = s_ekin(count); d_epot = s_depot(count); dd_epot = s_ddepot(count)
+    etot = epot + ekin
+    if (step > warmup_steps .and. mod(step, output_interval) == 0) then
+      num_samples = num_samples + 1
+      temp_inst = 2.d0 * ekin / (3.d0 * npd)                               ! md_means.f90:221
+      press_inst = rho * temp_inst + (-d_epot) / (3.d0 * params%volume)    ! md_means.f90:227, virial = -d_epot (:366)
+      write(iu_out, '(1pe13.6,5(2x,1pe13.6))') time, epot, ekin, etot, temp_inst, press_inst
+      call ljmd_check(ljmd_get_state(engine, c_loc(state%rx), c_loc(state%ry), c_loc(state%rz), &
+                                     c_loc(rux), c_loc(ruy), c_loc(ruz), &
+                                     c_loc(state%vx), c_loc(state%vy), c_loc(state%vz), &
+                                     c_loc(state%ax), c_loc(state%ay), c_loc(state%az)), engine, 'ljmd_get_state')
+      write(iu_rva) state%rx, state%ry, state%rz
+      write(iu_rva) rux, ruy, ruz
+      write(iu_rva) state%vx, state%vy, state%vz
+      write(iu_rva) state%ax, state%ay, state%az
+    end if
+  end do
+  call system_clock(c1)
+  close(iu_out)
+  close(iu_rva)
+  call ljmd_destroy(engine)
+
+  if (num_samples <= 0) stop 'md_simulation: no samples were taken (check warmup_steps/output_interval).'
+  write(*, '(a,i0,a,i0,a,f10.2,a,es11.4,a)') 'md_simulation_gpu: N=', params%n, ' steps=', total_steps, &
+    '  ', dble(total_steps) * dble(crate) / dble(max(c1 - c0, 1_8)), ' steps/s  ', &
+    0.5d0 * npd * (npd - 1.d0) * dble(total_steps) * dble(crate) / dble(max(c1 - c0, 1_8)), ' pair-interactions/s'
+
+contains
+
+  ! outputs/rv_init.dat: record 1 = rx ry rz, record 2 = vx vy vz (md_initial_config_program.f90:285-286)
+  subroutine read_rv_init(filename)
+    character(len=*), intent(in) :: filename
+    integer :: iu, ierr
+    open(newunit=iu, file=filename, form='unformatted', status='old', action='read', iostat=ierr)
+    if (ierr /= 0) stop 'read_rv_init(): cannot open rv_init file.'
+    read(iu) state%rx, state%ry, state%rz
+    read(iu) state%vx, state%vy, state%vz
+    close(iu)
+  end subroutine read_rv_init
+
+end program md_simulation_gpu

@@ -188,6 +188,22 @@ class Engine:
     def stream(self) -> int:
         return self._lib.ljmd_stream(self._h)
 
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.load().ljmd_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes) -> None:
+        assert len(unique_id) == _lib.COMM_ID_BYTES
+        self._ck(self._lib.ljmd_comm_init(self._h, unique_id))
+
+    def allgather_positions(self) -> None:
+        self._ck(self._lib.ljmd_allgather_positions(self._h))
+
+    def synchronize(self) -> None:
+        self._ck(self._lib.ljmd_synchronize(self._h))
+
     def step_begin(self) -> None:
         self._ck(self._lib.ljmd_step_begin(self._h))
 

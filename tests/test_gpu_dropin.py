@@ -1,0 +1,115 @@
+"""-m gpu: the Fortran side of the boundary.
+
+1. bin/md_simulation_gpu -- our thin Fortran driver (ISO_C_BINDING -> libljmd.so), BASELINE
+   config 1 end to end from the reference's own input file and rv_init.dat.
+2. oracle/_ref/md_simulation_program_gpu and md_initial_config_program_gpu -- the REFERENCE's
+   unmodified main programs and base/stats modules, compiled (in the build container, where
+   /root/reference exists) against OUR drop-in modules lj_potential_energy / verlet: the
+   literal "swap two files, link -lljmd" integration of INTEGRATION.md.  Compared with the
+   files the pure reference wrote (tests/golden/ref_run_n108_*).
+"""
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from ljmd_amd import io_formats
+
+pytestmark = pytest.mark.gpu
+
+PKG = ROOT / "molecular-dynamics-simulation---lennard-jones-monoatomic-fluid_amd"
+REF = ROOT / "oracle" / "_ref"
+
+
+def _workdir(tmp_path, tag):
+    src = GOLDEN / f"ref_run_n108_{tag}"
+    (tmp_path / "inputs").mkdir()
+    (tmp_path / "outputs" / "one_run").mkdir(parents=True)
+    shutil.copy(src / "input_simulation_parameters.txt", tmp_path / "inputs")
+    shutil.copy(src / "rv_init.dat", tmp_path / "outputs")
+    return src
+
+
+def _compare_run(tmp_path, src, n_rows):
+    mine = io_formats.read_energies(tmp_path / "outputs" / "one_run" / "instantaneous_energies.dat")
+    ref = io_formats.read_energies(src / "instantaneous_energies.dat")
+    assert mine.shape == ref.shape == (n_rows, 6)
+    # text file: 7 significant digits; up to step 1000 the GPU stays within ~1e-7 of the reference
+    assert np.allclose(mine, ref, rtol=5e-6, atol=0), np.max(np.abs(mine - ref) / np.abs(ref))
+    head = (tmp_path / "outputs" / "one_run" / "instantaneous_energies.dat").read_text().splitlines()[0]
+    assert head == "# time   epot   ekin   etot   T   P"
+
+
+def test_thin_fortran_driver_config1(tmp_path):
+    exe = PKG / "bin" / "md_simulation_gpu"
+    assert exe.exists(), "run __graft_entry__.build() first"
+    src = _workdir(tmp_path, "oi100")
+    out = subprocess.run([str(exe)], cwd=tmp_path, check=True, capture_output=True, text=True, timeout=120)
+    assert "steps/s" in out.stdout
+    _compare_run(tmp_path, src, 9)
+    h1, s1 = io_formats.read_rva(tmp_path / "outputs" / "one_run" / "rva.dat")
+    h2, s2 = io_formats.read_rva(src / "rva.dat")
+    assert h1 == h2 and s1.shape == s2.shape
+    assert (tmp_path / "outputs" / "one_run" / "rva.dat").stat().st_size == (src / "rva.dat").stat().st_size == 93636
+    assert np.abs(s1[0] - s2[0]).max() < 1e-9        # snapshot at step 200
+    # byte-identical row formatting of the first sample (identical digits at 7 significant figures)
+    l1 = (tmp_path / "outputs" / "one_run" / "instantaneous_energies.dat").read_text().splitlines()[1]
+    l2 = (src / "instantaneous_energies.dat").read_text().splitlines()[1]
+    assert l1 == l2
+
+
+def test_thin_fortran_driver_error_convention(tmp_path):
+    """Missing outputs/one_run -> the reference's `stop` message (md_simulation_program.f90:250)."""
+    exe = PKG / "bin" / "md_simulation_gpu"
+    src = GOLDEN / "ref_run_n108_oi100"
+    (tmp_path / "inputs").mkdir()
+    (tmp_path / "outputs").mkdir()
+    shutil.copy(src / "input_simulation_parameters.txt", tmp_path / "inputs")
+    shutil.copy(src / "rv_init.dat", tmp_path / "outputs")
+    out = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    # `stop 'text'` exits with status 0 under flang, exactly like the reference's own programs
+    assert "cannot open outputs/one_run/rva.dat" in (out.stdout + out.stderr)
+    assert not (tmp_path / "outputs" / "one_run").exists()
+
+
+@pytest.mark.skipif(not (REF / "md_simulation_program_gpu").exists(),
+                    reason="drop-in binary is built only where /root/reference exists")
+def test_reference_main_program_with_gpu_shim(tmp_path):
+    """The reference's own md_simulation_program.f90 + md_means/md_correlations/..., with only
+    lj_potential_energy.f90 and verlet.f90 swapped for our shim."""
+    src = _workdir(tmp_path, "oi10")
+    subprocess.run([str(REF / "md_simulation_program_gpu")], cwd=tmp_path, check=True, timeout=300)
+    _compare_run(tmp_path, src, 90)
+    # the reference's own summary file is produced by its own statistics code on our numbers
+    mine = (tmp_path / "outputs" / "one_run" / "md_final_results.txt").read_text().split()
+    ref = (src / "md_final_results.txt").read_text().split()
+    assert len(mine) == len(ref)
+    nums = [(float(a), float(b)) for a, b in zip(mine, ref) if _isnum(a) and _isnum(b)]
+    assert len(nums) >= 10
+    # means over 90 samples agree far inside their own statistical error
+    for a, b in nums[:6]:
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1.0), (a, b)
+
+
+@pytest.mark.skipif(not (REF / "md_initial_config_program_gpu").exists(),
+                    reason="drop-in binary is built only where /root/reference exists")
+def test_reference_init_program_with_gpu_shim(tmp_path):
+    """Second caller of the hot path (md_initial_config_program.f90:91,104,113-116): FCC lattice,
+    ran3 velocities, rescale, 100 warm-up verlet_step calls -- through the GPU shim."""
+    src = _workdir(tmp_path, "oi10")
+    (tmp_path / "outputs" / "rv_init.dat").unlink()
+    subprocess.run([str(REF / "md_initial_config_program_gpu")], cwd=tmp_path, check=True, timeout=300)
+    r1, v1 = io_formats.read_rv_init(tmp_path / "outputs" / "rv_init.dat", 108)
+    r2, v2 = io_formats.read_rv_init(src / "rv_init.dat", 108)
+    assert np.abs(r1 - r2).max() < 1e-10 and np.abs(v1 - v2).max() < 1e-9
+
+
+def _isnum(s):
+    try:
+        float(s)
+        return True
+    except ValueError:
+        return False

@@ -1,0 +1,101 @@
+"""-m gpu: the multi-rank device path on ONE GPU.
+
+The driver's 8-GPU node is the only place where >1 rank can own a card, so the sharded
+kernels (row shard vs all-N columns, shard-blocked exchange buffer, per-rank partial records)
+are exercised here by running G engines with rank = 0..G-1 on device 0 and performing the
+all-gather with device-to-device copies; the collective itself is covered by the gloo test
+(tests/test_distributed_gloo.py) and by a 1-rank RCCL communicator below.
+"""
+import numpy as np
+import pytest
+
+import ljmd_amd
+from ljmd_amd import Engine, distributed, init_params, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _emulated_allgather(engines):
+    """hipMemcpy device-to-device of every rank's own block into every other rank's exchange buffer
+    (same HIP runtime as libljmd.so: libamdhip64.so.7 is already loaded by it)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    for e in engines:
+        e.synchronize()
+    for src in engines:
+        sp, _tot, off, cnt = src.exchange_buffer()
+        for dst in engines:
+            if dst is not src:
+                dp = dst.exchange_buffer()[0]
+                assert hip.hipMemcpy(dp + 8 * off, sp + 8 * off, 8 * cnt, 3) == 0      # hipMemcpyDeviceToDevice
+    assert hip.hipDeviceSynchronize() == 0
+
+
+@pytest.mark.parametrize("n,G", [(4096, 2), (4096, 4), (3000, 3)])
+def test_sharded_engines_match_single_engine(n, G):
+    p, r, v = synthetic.make_config(n, seed=5)
+    nsteps = 15
+    with Engine(p) as one:
+        one.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e0 = one.compute_forces()
+        ref = np.stack(one.verlet_steps(nsteps), axis=1)
+        ref_state = one.get_state()
+
+    engines = [Engine(p, rank=g, n_ranks=G) for g in range(G)]
+    try:
+        for e in engines:
+            e.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        _emulated_allgather(engines)                   # every rank re-ordered its own block
+        for e in engines:
+            e.forces_partial()
+        parts0 = np.stack([e.read_partials(1)[0] for e in engines])
+        t0 = engines[0].combine_scalars(parts0)
+        assert np.allclose([t0[0], t0[2], t0[3]], e0, rtol=1e-13, atol=0)
+        for _ in range(nsteps):
+            for e in engines:
+                e.step_begin()
+            _emulated_allgather(engines)
+            for e in engines:
+                e.step_finish()
+        parts = np.stack([e.read_partials(nsteps) for e in engines])          # [G, nsteps, 8]
+        sc = np.array([engines[0].combine_scalars(np.ascontiguousarray(parts[:, s])) for s in range(nsteps)])
+        assert np.max(np.abs(sc - ref) / np.abs(ref)) < 1e-11
+        S = n // G
+        for g, e in enumerate(engines):
+            assert e.shard_range() == (g * S, (g + 1) * S)
+            st = e.get_state()
+            for key in ("r", "ru", "v", "a"):
+                mine = np.stack(st[key])
+                want = np.stack(ref_state[key])[:, g * S:(g + 1) * S]
+                scale = max(np.abs(want).max(), 1.0)
+                assert np.abs(mine - want).max() < 1e-9 * scale, (g, key)
+        with pytest.raises(ljmd_amd.LjmdError):
+            engines[0].allgather_positions()           # n_ranks > 1 without ljmd_comm_init
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_rccl_communicator_single_rank():
+    """The in-library RCCL path with a 1-rank communicator (all this box can host): unique id,
+    ncclCommInitRank, the in-place ncclAllGather on the engine's stream, teardown."""
+    uid = Engine.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    p, r, v = synthetic.make_config(4096, seed=8)
+    with Engine(p) as eng, Engine(p) as ref:
+        eng.comm_init(uid)
+        with pytest.raises(ljmd_amd.LjmdError):
+            eng.comm_init(uid)                          # already initialised
+        sim = distributed.ShardedSimulation(eng, 0, 1)
+        e0 = sim.start(r, v)
+        # call the collective by hand on the 1-rank communicator: must be a no-op copy in place
+        before = np.stack(eng.get_state(("r",))["r"])
+        eng._ck(eng._lib.ljmd_allgather_positions(eng._h))
+        eng.synchronize()
+        assert np.array_equal(before, np.stack(eng.get_state(("r",))["r"]))
+        sc = sim.run(5)
+        ref.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert ref.compute_forces() == e0
+        assert np.array_equal(np.stack(sc), np.stack(ref.verlet_steps(5)))
