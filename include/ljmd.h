@@ -177,11 +177,26 @@ void *ljmd_stream(ljmd_t *h);
 /* Phase 1: drift + wrap + half-kick + unwrapped update of the owned shard; the new
  * positions are written into the own block of the exchange buffer. */
 int ljmd_step_begin(ljmd_t *h);
-/* Phase 2 (after the all-gather): pair forces for the owned rows against all n
- * positions, second half-kick, per-rank partial sums appended to the scalar ring. */
+/*
+ * Phase 2 (after the all-gather): pair forces of this rank's share of the pair matrix
+ * against all n positions; with the Newton-3 kernel on n_ranks > 1 the library then sums
+ * the partial accelerations across ranks with ONE ncclReduceScatter of 3*P doubles per rank
+ * on the handle's stream; second half-kick; per-rank partial sums appended to the scalar ring.
+ */
 int ljmd_step_finish(ljmd_t *h);
 /* Pair forces only (t = 0 evaluation) on the exchange buffer contents. */
 int ljmd_forces_partial(ljmd_t *h);
+/*
+ * Test / integration hooks.  ljmd_step_forces runs only the pair kernel + slab reduction of
+ * phase 2 (ljmd_step_finish / ljmd_forces_partial then continue from there).  ljmd_force_buffers
+ * exposes the partial-acceleration buffer fpart ([n_ranks][3][P], block g = contributions to
+ * rank g's particles) and the receive buffer frecv ([3][P]); with external != 0 the library
+ * skips its own reduce-scatter and expects the caller to have written sum_ranks fpart[g] into
+ * rank g's frecv before ljmd_step_finish (used to emulate several ranks on one GPU).
+ */
+int ljmd_step_forces(ljmd_t *h);
+int ljmd_force_buffers(ljmd_t *h, int32_t external, void **fpart, int64_t *fpart_doubles,
+                       void **frecv, int64_t *frecv_doubles);
 /*
  * Copies out the raw per-rank partial records of the last `nsteps` finished phases,
  * LJMD_PARTIAL_STRIDE (8) doubles each: { sum r^-12, sum r^-6 over this rank's ordered

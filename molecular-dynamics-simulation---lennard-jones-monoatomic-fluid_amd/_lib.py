@@ -70,6 +70,9 @@ PROTOTYPES = {
     "ljmd_step_begin": (C.c_int, [C.c_void_p]),
     "ljmd_step_finish": (C.c_int, [C.c_void_p]),
     "ljmd_forces_partial": (C.c_int, [C.c_void_p]),
+    "ljmd_step_forces": (C.c_int, [C.c_void_p]),
+    "ljmd_force_buffers": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), c_int64_p,
+                                     C.POINTER(C.c_void_p), c_int64_p]),
     "ljmd_read_partials": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "ljmd_combine_scalars": (C.c_int, [C.c_void_p, c_double_p, C.c_int32] + [c_double_p] * 4),
     "ljmd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -86,9 +86,15 @@ struct ljmd {
     int nslab_t = 1, chunk_t = 0;     // tile kernel:    grid (TB/4, nslab_t), chunk_t mask words per slice
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
-    int NG = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
+    int NG = 0, NGo = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
     double *d_slab_j = nullptr;
     unsigned char *d_flag_j = nullptr;
+    // reduced raw accelerations: fpart [G or 1][3][P]; frecv [3][P] = reduce-scatter result (G > 1, Newton-3)
+    double *d_fpart = nullptr, *d_frecv = nullptr;
+    bool forces_pending = false;      // pair kernel + slab reduction enqueued, kick not yet
+    bool external_force_exchange = false;   // tests: the caller sums fpart over ranks into frecv
+    int pending_n_wg = 0;
+    double pending_scale = 0.5;
     int n_ke = 0;
 
     double *h_stage = nullptr;    // pinned, 3*G*P doubles
@@ -184,7 +190,7 @@ N3Args n3_args(ljmd_t *h)
     a.T = h->T;
     a.W = h->W;
     a.NG = h->NG;
-    a.NGown = h->NG;
+    a.NGo = h->NGo;
     a.Dmax = h->Dmax;
     a.Q = h->Q;
     a.dchunk = h->dchunk;
@@ -194,28 +200,43 @@ N3Args n3_args(ljmd_t *h)
     return a;
 }
 
-IntegrateArgs integrate_args(ljmd_t *h, int nslab, bool n3 = false)
+bool needs_force_exchange(const ljmd_t *h) { return h->use_n3 && h->G > 1; }
+
+IntegrateArgs integrate_args(ljmd_t *h)
 {
     IntegrateArgs a;
-    a.slab_j = n3 ? h->d_slab_j : nullptr;
-    a.flag_j = n3 ? h->d_flag_j : nullptr;
-    a.NG = h->NG;
-    a.Dmax = h->Dmax;
-    a.Q = h->Q;
     a.r = own_block(h);
     a.ru = h->d_ru;
     a.v = h->d_v;
     a.a = h->d_a;
-    a.slab = h->d_slab;
+    a.fsum = needs_force_exchange(h) ? h->d_frecv : h->d_fpart;
     a.ke_part = h->d_ke_part;
     a.rows = h->P;
     a.P = h->P;
-    a.nslab = nslab;
     a.L = h->L;
     a.invL = h->invL;
     a.dt = h->dt;
     a.dt_half = h->dt_half;
     a.dt_sq_half = h->dt_sq_half;
+    return a;
+}
+
+ReduceArgs reduce_args(ljmd_t *h, int nslab, bool n3)
+{
+    ReduceArgs a;
+    a.slab = h->d_slab;
+    a.slab_j = n3 ? h->d_slab_j : nullptr;
+    a.flag_j = n3 ? h->d_flag_j : nullptr;
+    a.fpart = h->d_fpart;
+    a.nslab = nslab;
+    a.P = h->P;
+    a.G = h->G;
+    a.rank = h->rank;
+    a.TB = h->TB;
+    a.NG = h->NG;
+    a.NGo = h->NGo;
+    a.Dmax = h->Dmax;
+    a.Q = h->Q;
     return a;
 }
 
@@ -282,8 +303,8 @@ int refresh_perm(ljmd_t *h)
     return LJMD_OK;
 }
 
-// forces on the owned rows from the exchange buffer; a <- 24 * sum(slabs)
-int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
+// Phase A: pair kernel on the exchange buffer + deterministic slab reduction into fpart.
+int enqueue_pair_forces(ljmd_t *h, EventSet *q)
 {
     const bool fast = fast_path_ok(h);
     if (q) LJMD_HIP(h, hipEventRecord(q->e[1], h->stream));
@@ -295,7 +316,7 @@ int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
         LJMD_HIP(h, launch_tile_mask(ga, h->stream));
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
-            const dim3 grid((h->NG + kWavesPerBlock - 1) / kWavesPerBlock, h->nslab_n);
+            const dim3 grid((h->NGo + kWavesPerBlock - 1) / kWavesPerBlock, h->nslab_n);
             LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->stream));
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y;
@@ -307,6 +328,9 @@ int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
             n_wg = grid.x * grid.y;
         }
     } else {
+        if (h->use_n3 && h->G > 1)
+            return fail(h, LJMD_ERR_STATE,
+                        "multi-rank Newton-3 run needs wrapped positions and rc <= (1-1e-9) L/2 (set LJMD_N3=0)");
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         const dim3 grid(h->P / kBlock, h->nslab_g);
         LJMD_HIP(h, launch_pair_rows_generic(pair_args(h, false), grid, h->stream));
@@ -314,18 +338,42 @@ int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
         n_wg = grid.x * grid.y;
     }
     if (q) LJMD_HIP(h, hipEventRecord(q->e[3], h->stream));
-    LJMD_HIP(h, launch_reduce_kick(integrate_args(h, nslab, n3), kick, h->stream));
-    LJMD_HIP(h, launch_finalize(finalize_args(h, n_wg, kick, n3 ? 1.0 : 0.5), h->stream));
+    LJMD_HIP(h, launch_reduce_forces(reduce_args(h, nslab, n3), needs_force_exchange(h), h->stream));
+    h->forces_pending = true;
+    h->pending_n_wg = n_wg;
+    h->pending_scale = n3 ? 1.0 : 0.5;
+    return LJMD_OK;
+}
+
+// Phase B: (multi-rank Newton-3) reduce-scatter of the partial accelerations, then x24, optional
+// second half-kick, kinetic-energy partials and this step's partial record.
+int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
+{
+    if (needs_force_exchange(h) && !h->external_force_exchange) {
+        if (!h->comm) return fail(h, LJMD_ERR_STATE, "multi-rank Newton-3 step: call ljmd_comm_init first");
+        const ncclResult_t r = ncclReduceScatter(h->d_fpart, h->d_frecv, 3 * (size_t)h->P, ncclDouble, ncclSum,
+                                                 h->comm, h->stream);
+        if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclReduceScatter failed: %s", ncclGetErrorString(r));
+    }
+    LJMD_HIP(h, launch_kick(integrate_args(h), kick, h->stream));
+    LJMD_HIP(h, launch_finalize(finalize_args(h, h->pending_n_wg, kick, h->pending_scale), h->stream));
     if (q) LJMD_HIP(h, hipEventRecord(q->e[4], h->stream));
     h->ring_issued++;
     h->have_accel = true;
+    h->forces_pending = false;
     return LJMD_OK;
+}
+
+int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
+{
+    const int rc_ = enqueue_pair_forces(h, q);
+    return rc_ != LJMD_OK ? rc_ : enqueue_kick(h, kick, q);
 }
 
 int enqueue_drift(ljmd_t *h, EventSet *q)
 {
     if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
-    LJMD_HIP(h, launch_drift_kick(integrate_args(h, 1), h->stream));
+    LJMD_HIP(h, launch_drift_kick(integrate_args(h), h->stream));
     h->positions_compact = true;  // freshly wrapped into [0, L]
     if (h->sort_enabled && fast_path_ok(h) && ++h->steps_since_sort >= h->resort_every)
         return resort(h, false);  // a(t) is dead after the drift/kick: K3 rewrites it
@@ -383,7 +431,7 @@ void release(ljmd_t *h)
         for (auto &e : q.e) (void)hipEventDestroy(e);
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
-                   h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j};
+                   h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -506,20 +554,21 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->chunk_t = (h->W + ns - 1) / ns;
         h->nslab_t = (h->W + h->chunk_t - 1) / h->chunk_t;
     }
-    {   // Newton-3 kernel: single rank, enough row groups to fill the chip
-        h->NG = h->T / kRowTiles;
+    {   // Newton-3 kernel: NG row groups over all ranks, NGo owned; offsets 0..Dmax in slices
+        h->NGo = h->TB / kRowTiles;
+        h->NG = h->G * h->NGo;
         h->Dmax = h->NG / 2;
         h->Q = (h->Dmax + 1) * kRowTiles;
         const int n3_min = env_int("LJMD_N3_MIN_N", 16384);
-        h->use_n3 = (h->G == 1) && env_int("LJMD_N3", 1) != 0 && n >= n3_min;
-        int ns = (8192 + h->NG - 1) / h->NG;
+        h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min;
+        int ns = (8192 + h->NGo - 1) / h->NGo;
         ns = std::max(1, std::min(ns, h->Dmax + 1));
         h->dchunk = (h->Dmax + 1 + ns - 1) / ns;
         h->nslab_n = (h->Dmax + 1 + h->dchunk - 1) / h->dchunk;
     }
     const int nslab_max = std::max(std::max(h->nslab_g, h->nslab_t), h->use_n3 ? h->nslab_n : 1);
     const int n_wg_max = std::max(row_blocks * std::max(h->nslab_g, h->nslab_t),
-                                  ((h->NG + kWavesPerBlock - 1) / kWavesPerBlock) * h->nslab_n);
+                                  ((h->NGo + kWavesPerBlock - 1) / kWavesPerBlock) * h->nslab_n);
     h->n_ke = row_blocks;
     h->h_perm.resize(h->P);
     for (int i = 0; i < h->P; ++i) h->h_perm[i] = i;
@@ -536,10 +585,12 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_slab, P3 * nslab_max));
         LJMD_HIP(h, hipMalloc(&h->d_wg_part, 2 * (size_t)n_wg_max * sizeof(double)));
         if (h->use_n3) {
-            LJMD_HIP(h, hipMalloc(&h->d_slab_j, (size_t)h->NG * h->Q * 3 * kTile * sizeof(double)));
-            LJMD_HIP(h, hipMalloc(&h->d_flag_j, (size_t)h->NG * h->Q));
-            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, (size_t)h->NG * h->Q, h->stream));
+            LJMD_HIP(h, hipMalloc(&h->d_slab_j, (size_t)h->NGo * h->Q * 3 * kTile * sizeof(double)));
+            LJMD_HIP(h, hipMalloc(&h->d_flag_j, (size_t)h->NGo * h->Q));
+            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, (size_t)h->NGo * h->Q, h->stream));
         }
+        LJMD_HIP(h, hipMalloc(&h->d_fpart, P3 * (needs_force_exchange(h) ? h->G : 1)));
+        if (needs_force_exchange(h)) LJMD_HIP(h, hipMalloc(&h->d_frecv, P3));
         LJMD_HIP(h, hipMalloc(&h->d_ke_part, 3 * (size_t)h->n_ke * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring, (size_t)kRingCap * kPartialStride * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring_pos, sizeof(unsigned)));
@@ -730,7 +781,7 @@ int ljmd_kinetic_energy(ljmd_t *h, double *ekin)
     if (!h || !ekin) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_kinetic_energy: NULL argument");
     if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_kinetic_energy: no state has been set");
     LJMD_HIP(h, hipSetDevice(h->device));
-    LJMD_HIP(h, launch_kinetic_fused(integrate_args(h, 1), h->stream));
+    LJMD_HIP(h, launch_kinetic_fused(integrate_args(h), h->stream));
     std::vector<double> part(3 * (size_t)h->n_ke);
     LJMD_HIP(h, hipMemcpyAsync(part.data(), h->d_ke_part, part.size() * sizeof(double),
                                hipMemcpyDeviceToHost, h->stream));
@@ -785,14 +836,39 @@ int ljmd_step_begin(ljmd_t *h)
     return enqueue_drift(h, next_events(h));
 }
 
+int ljmd_step_forces(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_step_forces: NULL handle");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_step_forces: no state has been set");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    // pairs with the event set taken by ljmd_step_begin (the last one handed out)
+    EventSet *q = (h->profiling && h->ev_used > 0) ? &h->ev_pool[h->ev_used - 1] : nullptr;
+    return enqueue_pair_forces(h, q);
+}
+
 int ljmd_step_finish(ljmd_t *h)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_step_finish: NULL handle");
     if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_step_finish: no state has been set");
     LJMD_HIP(h, hipSetDevice(h->device));
-    // pairs with the event set taken by ljmd_step_begin (the last one handed out)
     EventSet *q = (h->profiling && h->ev_used > 0) ? &h->ev_pool[h->ev_used - 1] : nullptr;
-    return enqueue_forces(h, true, q);
+    if (!h->forces_pending) {
+        const int rc_ = enqueue_pair_forces(h, q);
+        if (rc_ != LJMD_OK) return rc_;
+    }
+    return enqueue_kick(h, true, q);
+}
+
+int ljmd_force_buffers(ljmd_t *h, int32_t external, void **fpart, int64_t *fpart_doubles, void **frecv,
+                       int64_t *frecv_doubles)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_force_buffers: NULL handle");
+    h->external_force_exchange = external != 0;
+    if (fpart) *fpart = h->d_fpart;
+    if (fpart_doubles) *fpart_doubles = 3 * (int64_t)h->P * (needs_force_exchange(h) ? h->G : 1);
+    if (frecv) *frecv = h->d_frecv;
+    if (frecv_doubles) *frecv_doubles = needs_force_exchange(h) ? 3 * (int64_t)h->P : 0;
+    return LJMD_OK;
 }
 
 int ljmd_forces_partial(ljmd_t *h)
@@ -800,7 +876,11 @@ int ljmd_forces_partial(ljmd_t *h)
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_forces_partial: NULL handle");
     if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_forces_partial: no state has been set");
     LJMD_HIP(h, hipSetDevice(h->device));
-    return enqueue_forces(h, false, nullptr);
+    if (!h->forces_pending) {
+        const int rc_ = enqueue_pair_forces(h, nullptr);
+        if (rc_ != LJMD_OK) return rc_;
+    }
+    return enqueue_kick(h, false, nullptr);
 }
 
 int ljmd_read_partials(ljmd_t *h, int32_t nsteps, double *partial)

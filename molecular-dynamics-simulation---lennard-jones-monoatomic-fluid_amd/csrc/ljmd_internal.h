@@ -47,11 +47,11 @@ struct N3Args {
     const double *pos;      // exchange buffer
     const uint64_t *mask;   // [T rows][W] tile-pair mask (all row tiles, not only the owned ones)
     double *slab_i;         // [nchunk][3][P] partial accelerations of the owned rows (row side)
-    double *slab_j;         // [NGown][Q][3][64] column-side partial accelerations, Q = (Dmax+1)*4
-    unsigned char *flag_j;  // [NGown][Q] 1 = slab_j block written this step
+    double *slab_j;         // [NGo][Q][3][64] column-side partial accelerations, Q = (Dmax+1)*4
+    unsigned char *flag_j;  // [NGo][Q] 1 = slab_j block written this step
     double *wg_part;        // [n workgroups][2]
     int P, G, rank, TB, T, W;
-    int NG, NGown, Dmax, Q; // groups in total / owned by this rank
+    int NG, NGo, Dmax, Q;   // row groups in total / owned by this rank (NGo = TB / 4, NG = G * NGo)
     int dchunk;             // offsets d per grid.y slice
     double L, invL, rc2;
 };
@@ -59,15 +59,24 @@ struct N3Args {
 struct IntegrateArgs {
     double *r;              // own block of the exchange buffer, axis stride = P
     double *ru, *v, *a;     // [3][P]
-    const double *slab;     // [nslab][3][P]
+    const double *fsum;     // [3][P] raw (prefactor-free) total accelerations of the owned rows
     double *ke_part;        // [n blocks][3]
-    // Newton-3 column-side slabs (NULL when the gather kernels produced the forces)
-    const double *slab_j;
-    const unsigned char *flag_j;
-    int NG, Dmax, Q;
     int rows;               // = P (padding included: it integrates to NaN / 0 harmlessly)
-    int P, nslab;
+    int P;
     double L, invL, dt, dt_half, dt_sq_half;
+};
+
+// Deterministic reduction of the pair kernels' partial-acceleration slabs into fpart.
+// Gather kernels / single rank: fpart = [1][3][P] (own rows).  Newton-3 on G > 1 ranks:
+// fpart = [G][3][P], block g = this rank's contributions to rank g's particles (own block:
+// row side + column side, remote blocks: column side only); an RCCL reduce-scatter then sums
+// block g over the ranks into rank g's fsum.
+struct ReduceArgs {
+    const double *slab;     // row side [nslab][3][P]
+    const double *slab_j;   // column side (Newton-3) or NULL
+    const unsigned char *flag_j;
+    double *fpart;
+    int nslab, P, G, rank, TB, NG, NGo, Dmax, Q;
 };
 
 struct FinalizeArgs {
@@ -100,7 +109,8 @@ hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s)
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_n3(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s);
-hipError_t launch_reduce_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
+hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);
+hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);

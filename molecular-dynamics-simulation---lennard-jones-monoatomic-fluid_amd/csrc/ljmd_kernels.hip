@@ -310,19 +310,21 @@ __global__ __launch_bounds__(kBlock, 4) void pair_n3_kernel(N3Args a)
     __shared__ double red[2 * kWavesPerBlock];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int A = blockIdx.x * kWavesPerBlock + wave;          // row group, wave-uniform
-    const bool active = A < a.NG;
+    const int Al = blockIdx.x * kWavesPerBlock + wave;         // owned row group, wave-uniform
+    const bool active = Al < a.NGo;
+    const int A = a.rank * a.NGo + Al;                         // its global index
     const size_t P = a.P;
+    const double *own = a.pos + (size_t)a.rank * 3 * P;
 
     double xi[kRowTiles], yi[kRowTiles], zi[kRowTiles];
     double ax[kRowTiles], ay[kRowTiles], az[kRowTiles];
     double s12 = 0.0, s6 = 0.0;
 #pragma unroll
     for (int k = 0; k < kRowTiles; ++k) {
-        const size_t slot = (size_t)(active ? kRowTiles * A + k : 0) * kTile + lane;
-        xi[k] = a.pos[slot];
-        yi[k] = a.pos[P + slot];
-        zi[k] = a.pos[2 * P + slot];
+        const size_t slot = (size_t)(active ? kRowTiles * Al + k : 0) * kTile + lane;
+        xi[k] = own[slot];
+        yi[k] = own[P + slot];
+        zi[k] = own[2 * P + slot];
         ax[k] = ay[k] = az[k] = 0.0;
     }
 
@@ -333,13 +335,13 @@ __global__ __launch_bounds__(kBlock, 4) void pair_n3_kernel(N3Args a)
         if (B >= a.NG) B -= a.NG;
         const bool own = (d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B);
         for (int l = 0; l < kRowTiles; ++l) {
-            const int c = kRowTiles * B + l;                   // column tile
-            const size_t blk = (size_t)A * a.Q + (size_t)d * kRowTiles + l;
+            const int c = kRowTiles * B + l;                   // column tile (global)
+            const size_t blk = (size_t)Al * a.Q + (size_t)d * kRowTiles + l;
             unsigned mb = 0;
             if (own) {
 #pragma unroll
                 for (int k = 0; k < kRowTiles; ++k) {
-                    const uint64_t w = a.mask[(size_t)(kRowTiles * A + k) * a.W + (c >> 6)];
+                    const uint64_t w = a.mask[(size_t)(kRowTiles * Al + k) * a.W + (c >> 6)];
                     mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
                 }
                 if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
@@ -348,8 +350,9 @@ __global__ __launch_bounds__(kBlock, 4) void pair_n3_kernel(N3Args a)
                 if (lane == 0) a.flag_j[blk] = 0;
                 continue;
             }
-            const size_t cs = (size_t)c * kTile + lane;
-            double xj = a.pos[cs], yj = a.pos[P + cs], zj = a.pos[2 * P + cs];
+            const int gj = (a.G == 1) ? 0 : c / a.TB;          // rank block holding the column tile
+            const double *cb = a.pos + (size_t)gj * 3 * P + (size_t)(c - gj * a.TB) * kTile + lane;
+            double xj = cb[0], yj = cb[P], zj = cb[2 * P];
             double jx = 0.0, jy = 0.0, jz = 0.0;
 
             if (d == 0 && ((mb >> l) & 1u)) {
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(kBlock, 4) void pair_n3_kernel(N3Args a)
         double *si = a.slab_i + (size_t)blockIdx.y * 3 * P;
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k) {
-            const size_t slot = (size_t)(kRowTiles * A + k) * kTile + lane;
+            const size_t slot = (size_t)(kRowTiles * Al + k) * kTile + lane;
             si[slot] = ax[k];
             si[P + slot] = ay[k];
             si[2 * P + slot] = az[k];
@@ -508,46 +511,64 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// K3: reduce the partial-acceleration slabs (row side, and for Newton-3 also the column-side
-// blocks addressed to this tile) in fixed order, restore the x24 prefactor
-// (lj_potential_energy.f90:189-191), optionally apply the second half-kick
-// (verlet.f90:86-88) and emit per-block partial sums of vx^2, vy^2, vz^2
-// (verlet.f90:93-95 keeps the three sums separate).
+// K3a: deterministic reduction of the partial-acceleration slabs (fixed order: row-side
+// slices, then column-side blocks by ascending owned row group).  See ReduceArgs.
+// grid = (P / 256, number of fpart blocks).
 // ---------------------------------------------------------------------------
-template <bool KICK, bool N3>
-__global__ __launch_bounds__(kBlock) void reduce_kick_kernel(IntegrateArgs a)
+template <bool N3>
+__global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
 {
-    __shared__ double red[3 * kWavesPerBlock];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    double k2[3] = {0.0, 0.0, 0.0};
-    if (i < a.rows) {
-        double s[3];
+    const int i = blockIdx.x * kBlock + threadIdx.x;            // slot inside the block
+    const int g = (gridDim.y == 1) ? a.rank : (int)blockIdx.y;  // whose particles
+    double s[3] = {0.0, 0.0, 0.0};
+    if (g == a.rank) {
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             const size_t o = (size_t)ax * a.P + i;
             s[ax] = a.slab[o];
             for (int c = 1; c < a.nslab; ++c) s[ax] += a.slab[(size_t)c * 3 * a.P + o];
         }
-        if constexpr (N3) {
-            // column-side blocks of this particle's tile, in fixed offset order d = 0 .. Dmax
-            const int c = i / kTile, lane = i - c * kTile;
-            const int B = c / kRowTiles, l = c - B * kRowTiles;
-            for (int d = 0; d <= a.Dmax; ++d) {
-                int A = B - d;
-                if (A < 0) A += a.NG;
-                const size_t blk = (size_t)A * a.Q + (size_t)d * kRowTiles + l;
-                if (a.flag_j[blk]) {
-                    const double *b = a.slab_j + blk * (3 * kTile) + lane;
-                    s[0] += b[0];
-                    s[1] += b[kTile];
-                    s[2] += b[2 * kTile];
-                }
+    }
+    if constexpr (N3) {
+        const int tl = i / kTile, lane = i - tl * kTile;
+        const int c = g * a.TB + tl;                            // global column tile
+        const int B = c / kRowTiles, l = c - B * kRowTiles;
+        const int A0 = a.rank * a.NGo;
+        for (int Al = 0; Al < a.NGo; ++Al) {
+            int d = B - (A0 + Al);
+            if (d < 0) d += a.NG;
+            if (d > a.Dmax) continue;
+            const size_t blk = (size_t)Al * a.Q + (size_t)d * kRowTiles + l;
+            if (a.flag_j[blk]) {
+                const double *b = a.slab_j + blk * (3 * kTile) + lane;
+                s[0] += b[0];
+                s[1] += b[kTile];
+                s[2] += b[2 * kTile];
             }
         }
+    }
+    double *o = a.fpart + (size_t)(gridDim.y == 1 ? 0 : g) * 3 * a.P + i;
+    o[0] = s[0];
+    o[a.P] = s[1];
+    o[2 * (size_t)a.P] = s[2];
+}
+
+// ---------------------------------------------------------------------------
+// K3b: restore the x24 prefactor (lj_potential_energy.f90:189-191), optionally apply the
+// second half-kick (verlet.f90:86-88) and emit per-block partial sums of vx^2, vy^2, vz^2
+// (verlet.f90:93-95 keeps the three sums separate).
+// ---------------------------------------------------------------------------
+template <bool KICK>
+__global__ __launch_bounds__(kBlock) void kick_kernel(IntegrateArgs a)
+{
+    __shared__ double red[3 * kWavesPerBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double k2[3] = {0.0, 0.0, 0.0};
+    if (i < a.rows) {
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             const size_t o = (size_t)ax * a.P + i;
-            const double acc = 24.0 * s[ax];
+            const double acc = 24.0 * a.fsum[o];
             a.a[o] = acc;
             if constexpr (KICK) {
                 const double v1 = a.v[o] + acc * a.dt_half;
@@ -662,18 +683,23 @@ hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_reduce_kick(const IntegrateArgs &a, bool kick, hipStream_t s)
+hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s)
+{
+    const dim3 grid(a.P / kBlock, all_blocks ? a.G : 1);
+    if (a.slab_j)
+        hipLaunchKernelGGL(reduce_forces_kernel<true>, grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(reduce_forces_kernel<false>, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s)
 {
     const dim3 grid((a.rows + kBlock - 1) / kBlock);
-    const bool n3 = a.slab_j != nullptr;
-    if (kick && n3)
-        hipLaunchKernelGGL((reduce_kick_kernel<true, true>), grid, dim3(kBlock), 0, s, a);
-    else if (kick)
-        hipLaunchKernelGGL((reduce_kick_kernel<true, false>), grid, dim3(kBlock), 0, s, a);
-    else if (n3)
-        hipLaunchKernelGGL((reduce_kick_kernel<false, true>), grid, dim3(kBlock), 0, s, a);
+    if (kick)
+        hipLaunchKernelGGL(kick_kernel<true>, grid, dim3(kBlock), 0, s, a);
     else
-        hipLaunchKernelGGL((reduce_kick_kernel<false, false>), grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(kick_kernel<false>, grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

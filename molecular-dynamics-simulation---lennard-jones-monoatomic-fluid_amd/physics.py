@@ -210,6 +210,17 @@ class Engine:
     def step_finish(self) -> None:
         self._ck(self._lib.ljmd_step_finish(self._h))
 
+    def step_forces(self) -> None:
+        self._ck(self._lib.ljmd_step_forces(self._h))
+
+    def force_buffers(self, external: bool):
+        """-> (fpart address, doubles, frecv address, doubles); see include/ljmd.h"""
+        fp, fr = C.c_void_p(), C.c_void_p()
+        nfp, nfr = C.c_int64(), C.c_int64()
+        self._ck(self._lib.ljmd_force_buffers(self._h, 1 if external else 0, C.byref(fp), C.byref(nfp),
+                                              C.byref(fr), C.byref(nfr)))
+        return fp.value, nfp.value, fr.value, nfr.value
+
     def forces_partial(self) -> None:
         self._ck(self._lib.ljmd_forces_partial(self._h))
 

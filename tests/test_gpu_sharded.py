@@ -15,13 +15,17 @@ from ljmd_amd import Engine, distributed, init_params, synthetic
 pytestmark = pytest.mark.gpu
 
 
-def _emulated_allgather(engines):
-    """hipMemcpy device-to-device of every rank's own block into every other rank's exchange buffer
-    (same HIP runtime as libljmd.so: libamdhip64.so.7 is already loaded by it)."""
+def _hip():
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so.7")
+    hip = C.CDLL("libamdhip64.so.7")       # already loaded by libljmd.so: same runtime instance
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipMemcpy.restype = C.c_int
+    return hip
+
+
+def _emulated_allgather(engines):
+    """hipMemcpy device-to-device of every rank's own block into every other rank's exchange buffer."""
+    hip = _hip()
     for e in engines:
         e.synchronize()
     for src in engines:
@@ -29,12 +33,37 @@ def _emulated_allgather(engines):
         for dst in engines:
             if dst is not src:
                 dp = dst.exchange_buffer()[0]
-                assert hip.hipMemcpy(dp + 8 * off, sp + 8 * off, 8 * cnt, 3) == 0      # hipMemcpyDeviceToDevice
+                assert hip.hipMemcpy(dp + 8 * off, sp + 8 * off, 8 * cnt, 3) == 0      # device to device
     assert hip.hipDeviceSynchronize() == 0
 
 
-@pytest.mark.parametrize("n,G", [(4096, 2), (4096, 4), (3000, 3)])
-def test_sharded_engines_match_single_engine(n, G):
+def _emulated_reduce_scatter(engines):
+    """What ncclReduceScatter(sum) does on a real node: frecv[g] = sum over ranks of fpart_rank[g]."""
+    hip = _hip()
+    G = len(engines)
+    for e in engines:
+        e.synchronize()
+    parts = []
+    for e in engines:
+        fp, nfp, _fr, nfr = e.force_buffers(True)
+        if nfr == 0:
+            return                                       # gather kernels: nothing to exchange
+        host = np.empty(nfp)
+        assert hip.hipMemcpy(host.ctypes.data, fp, 8 * nfp, 2) == 0                    # device to host
+        parts.append(host.reshape(G, -1))
+    for g, e in enumerate(engines):
+        tot = parts[0][g].copy()
+        for src in range(1, G):
+            tot += parts[src][g]
+        fr = e.force_buffers(True)[2]
+        assert hip.hipMemcpy(fr, tot.ctypes.data, 8 * tot.size, 1) == 0                # host to device
+    assert hip.hipDeviceSynchronize() == 0
+
+
+@pytest.mark.parametrize("n,G,n3", [(4096, 2, False), (4096, 4, False), (3000, 3, False),
+                                    (4096, 2, True), (4096, 4, True), (3000, 3, True), (8192, 8, True)])
+def test_sharded_engines_match_single_engine(n, G, n3, monkeypatch):
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1" if n3 else "100000000")
     p, r, v = synthetic.make_config(n, seed=5)
     nsteps = 15
     with Engine(p) as one:
@@ -46,8 +75,12 @@ def test_sharded_engines_match_single_engine(n, G):
     engines = [Engine(p, rank=g, n_ranks=G) for g in range(G)]
     try:
         for e in engines:
+            e.force_buffers(True)                      # the test performs the force exchange
             e.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         _emulated_allgather(engines)                   # every rank re-ordered its own block
+        for e in engines:
+            e.step_forces()
+        _emulated_reduce_scatter(engines)
         for e in engines:
             e.forces_partial()
         parts0 = np.stack([e.read_partials(1)[0] for e in engines])
@@ -57,6 +90,9 @@ def test_sharded_engines_match_single_engine(n, G):
             for e in engines:
                 e.step_begin()
             _emulated_allgather(engines)
+            for e in engines:
+                e.step_forces()
+            _emulated_reduce_scatter(engines)
             for e in engines:
                 e.step_finish()
         parts = np.stack([e.read_partials(nsteps) for e in engines])          # [G, nsteps, 8]
