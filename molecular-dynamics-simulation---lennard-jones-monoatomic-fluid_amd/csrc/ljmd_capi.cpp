@@ -78,6 +78,12 @@ struct ljmd {
     double *d_tmp3 = nullptr;     // [3][P]
     void *d_cub = nullptr;
     size_t cub_bytes = 0;
+    // k-d ordering (default): per level the segment boundaries in particle units
+    bool kd_sort = true;
+    std::vector<int> kd_level_nseg;       // segments at level l
+    std::vector<size_t> kd_level_off;     // offset of level l's boundaries inside d_kd_offsets
+    int *d_kd_offsets = nullptr;
+    unsigned long long *d_kd_keys = nullptr, *d_kd_keys2 = nullptr;   // [P]
 
     unsigned ring_consumed = 0;   // host mirror: records already read back
     unsigned ring_issued = 0;     // host mirror: finalize launches issued
@@ -86,6 +92,7 @@ struct ljmd {
     int nslab_t = 1, chunk_t = 0;     // tile kernel:    grid (TB/4, nslab_t), chunk_t mask words per slice
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
+    int n3_waves = 4;                 // LJMD_N3_WAVES: register-budget variant of the Newton-3 kernel
     int NG = 0, NGo = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
     double *d_slab_j = nullptr;
     unsigned char *d_flag_j = nullptr;
@@ -270,16 +277,33 @@ EventSet *next_events(ljmd_t *h)
 // asked) and compose the slot->original permutation.  Performance only (ljmd_sort.hip).
 int resort(ljmd_t *h, bool with_accel)
 {
-    SortArgs sa;
-    sa.r = own_block(h);
-    sa.keys = h->d_keys;
-    sa.idx = h->d_idx;
-    sa.S = h->S;
-    sa.P = h->P;
-    sa.ncell = h->ncell;
-    sa.L = h->L;
-    LJMD_HIP(h, launch_sort_keys(sa, h->stream));
-    LJMD_HIP(h, sort_pairs(h->d_cub, h->cub_bytes, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2, h->P, h->stream));
+    if (h->kd_sort) {
+        // recursive median split (ljmd_sort.hip): one segmented sort per level, axis = level % 3
+        LJMD_HIP(h, launch_iota(h->d_idx, h->P, h->stream));
+        LJMD_HIP(h, hipMemcpyAsync(h->d_idx2, h->d_idx, (size_t)h->P * sizeof(int), hipMemcpyDeviceToDevice,
+                                   h->stream));   // slots S..P-1 (padding) keep their identity in both buffers
+        int *cur = h->d_idx, *nxt = h->d_idx2;
+        for (size_t l = 0; l < h->kd_level_nseg.size(); ++l) {
+            const double *axis = own_block(h) + (size_t)(l % 3) * h->P;
+            LJMD_HIP(h, kd_level(h->d_cub, h->cub_bytes, axis, h->L, h->d_kd_keys, h->d_kd_keys2, cur, nxt, h->S,
+                                 h->kd_level_nseg[l], h->d_kd_offsets + h->kd_level_off[l], h->stream));
+            std::swap(cur, nxt);
+        }
+        if (cur != h->d_idx2)
+            LJMD_HIP(h, hipMemcpyAsync(h->d_idx2, cur, (size_t)h->P * sizeof(int), hipMemcpyDeviceToDevice,
+                                       h->stream));
+    } else {
+        SortArgs sa;
+        sa.r = own_block(h);
+        sa.keys = h->d_keys;
+        sa.idx = h->d_idx;
+        sa.S = h->S;
+        sa.P = h->P;
+        sa.ncell = h->ncell;
+        sa.L = h->L;
+        LJMD_HIP(h, launch_sort_keys(sa, h->stream));
+        LJMD_HIP(h, sort_pairs(h->d_cub, h->cub_bytes, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2, h->P, h->stream));
+    }
     const size_t bytes3 = 3 * (size_t)h->P * sizeof(double);
     double *sets[4] = {own_block(h), h->d_ru, h->d_v, h->d_a};
     for (int k = 0; k < (with_accel ? 4 : 3); ++k) {
@@ -317,7 +341,7 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
             const dim3 grid((h->NGo + kWavesPerBlock - 1) / kWavesPerBlock, h->nslab_n);
-            LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->stream));
+            LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->n3_waves, h->stream));
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y;
             n3 = true;
@@ -431,7 +455,8 @@ void release(ljmd_t *h)
         for (auto &e : q.e) (void)hipEventDestroy(e);
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
-                   h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv};
+                   h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv,
+                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -539,6 +564,28 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
     h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", 10));
     h->ncell = std::max(1, std::min(1023, (int)std::floor(box_length / 1.2)));
+    h->kd_sort = env_int("LJMD_SORT_KD", 1) != 0;
+    std::vector<int> kd_offsets;
+    {   // k-d levels: segments = runs of whole tiles, halved until every segment is one tile
+        const int tiles = (h->S + kTile - 1) / kTile;
+        std::vector<int> bounds = {0, tiles};
+        while (true) {
+            bool any = false;
+            for (size_t j = 0; j + 1 < bounds.size(); ++j) any = any || (bounds[j + 1] - bounds[j] > 1);
+            if (!any) break;
+            h->kd_level_off.push_back(kd_offsets.size());
+            h->kd_level_nseg.push_back((int)bounds.size() - 1);
+            for (int b : bounds) kd_offsets.push_back(std::min(b * kTile, h->S));
+            std::vector<int> next;
+            for (size_t j = 0; j + 1 < bounds.size(); ++j) {
+                next.push_back(bounds[j]);
+                const int t = bounds[j + 1] - bounds[j];
+                if (t > 1) next.push_back(bounds[j] + (t + 1) / 2);
+            }
+            next.push_back(tiles);
+            bounds.swap(next);
+        }
+    }
 
     // launch geometry: rows x slices >= kTargetWorkgroups
     const int row_blocks = h->P / kBlock;
@@ -561,6 +608,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->Q = (h->Dmax + 1) * kRowTiles;
         const int n3_min = env_int("LJMD_N3_MIN_N", 16384);
         h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min;
+        h->n3_waves = env_int("LJMD_N3_WAVES", 4);
         int ns = (8192 + h->NGo - 1) / h->NGo;
         ns = std::max(1, std::min(ns, h->Dmax + 1));
         h->dchunk = (h->Dmax + 1 + ns - 1) / ns;
@@ -602,8 +650,14 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_idx2, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, hipMalloc(&h->d_perm, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, hipMalloc(&h->d_perm2, (size_t)h->P * sizeof(int)));
-        h->cub_bytes = sort_temp_bytes(h->P);
+        h->cub_bytes = std::max(sort_temp_bytes(h->P), kd_temp_bytes(h->S));
         LJMD_HIP(h, hipMalloc(&h->d_cub, std::max<size_t>(h->cub_bytes, 16)));
+        LJMD_HIP(h, hipMalloc(&h->d_kd_keys, (size_t)h->P * sizeof(unsigned long long)));
+        LJMD_HIP(h, hipMalloc(&h->d_kd_keys2, (size_t)h->P * sizeof(unsigned long long)));
+        LJMD_HIP(h, hipMalloc(&h->d_kd_offsets, std::max<size_t>(kd_offsets.size(), 2) * sizeof(int)));
+        if (!kd_offsets.empty())
+            LJMD_HIP(h, hipMemcpyAsync(h->d_kd_offsets, kd_offsets.data(), kd_offsets.size() * sizeof(int),
+                                       hipMemcpyHostToDevice, h->stream));
         LJMD_HIP(h, hipMemsetAsync(h->d_ring_pos, 0, sizeof(unsigned), h->stream));
         LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, P3, h->stream));
         LJMD_HIP(h, hipMemsetAsync(h->d_ke_part, 0, 3 * (size_t)h->n_ke * sizeof(double), h->stream));

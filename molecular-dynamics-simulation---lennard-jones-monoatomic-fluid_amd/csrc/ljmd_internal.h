@@ -107,7 +107,7 @@ struct SortArgs {
 
 hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, hipStream_t s);
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);
 hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
@@ -121,6 +121,11 @@ size_t sort_temp_bytes(int count);
 hipError_t launch_sort_keys(const SortArgs &a, hipStream_t s);
 hipError_t sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out,
                       const int *idx_in, int *idx_out, int count, hipStream_t s);
+size_t kd_temp_bytes(int count);
+hipError_t launch_iota(int *idx, int P, hipStream_t s);
+hipError_t kd_level(void *temp, size_t temp_bytes, const double *coord_axis, double L, unsigned long long *keys,
+                    unsigned long long *keys_out, int *idx, int *idx_out, int S, int nseg, const int *seg_offsets,
+                    hipStream_t s);
 hipError_t launch_gather3(const double *src, double *dst, const int *idx, int P, hipStream_t s);
 hipError_t launch_gather_perm(const int *src, int *dst, const int *idx, int P, hipStream_t s);
 

@@ -305,7 +305,8 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
     }
 }
 
-__global__ __launch_bounds__(kBlock, 4) void pair_n3_kernel(N3Args a)
+template <int MIN_WAVES>
+__global__ __launch_bounds__(kBlock, MIN_WAVES) void pair_n3_kernel(N3Args a)
 {
     __shared__ double red[2 * kWavesPerBlock];
     const int lane = threadIdx.x & 63;
@@ -659,9 +660,15 @@ hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, hipStream_t s)
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s)
 {
-    hipLaunchKernelGGL(pair_n3_kernel, grid, dim3(kBlock), 0, s, a);
+    // register budget variants (occupancy vs spills); the default is chosen by measurement
+    if (min_waves <= 3)
+        hipLaunchKernelGGL(pair_n3_kernel<3>, grid, dim3(kBlock), 0, s, a);
+    else if (min_waves == 4)
+        hipLaunchKernelGGL(pair_n3_kernel<4>, grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(pair_n3_kernel<5>, grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 
