@@ -92,7 +92,7 @@ struct ljmd {
     int nslab_t = 1, chunk_t = 0;     // tile kernel:    grid (TB/4, nslab_t), chunk_t mask words per slice
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
-    int n3_waves = 4;                 // LJMD_N3_WAVES: register-budget variant of the Newton-3 kernel
+    int n3_waves = 3;                 // LJMD_N3_WAVES: register-budget variant of the Newton-3 kernel
     int NG = 0, NGo = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
     double *d_slab_j = nullptr;
     unsigned char *d_flag_j = nullptr;
@@ -186,6 +186,7 @@ N3Args n3_args(ljmd_t *h)
     N3Args a;
     a.pos = h->d_pos;
     a.mask = h->d_mask;
+    a.bbox = h->d_bbox;
     a.slab_i = h->d_slab;
     a.slab_j = h->d_slab_j;
     a.flag_j = h->d_flag_j;
@@ -608,8 +609,9 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->Q = (h->Dmax + 1) * kRowTiles;
         const int n3_min = env_int("LJMD_N3_MIN_N", 16384);
         h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min;
-        h->n3_waves = env_int("LJMD_N3_WAVES", 4);
-        int ns = (8192 + h->NGo - 1) / h->NGo;
+        h->n3_waves = env_int("LJMD_N3_WAVES", 3);
+        const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 32768));
+        int ns = (target_waves + h->NGo - 1) / h->NGo;
         ns = std::max(1, std::min(ns, h->Dmax + 1));
         h->dchunk = (h->Dmax + 1 + ns - 1) / ns;
         h->nslab_n = (h->Dmax + 1 + h->dchunk - 1) / h->dchunk;

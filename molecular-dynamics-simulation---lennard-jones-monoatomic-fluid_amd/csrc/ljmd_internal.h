@@ -45,7 +45,8 @@ struct PairArgs {
 // index), so every unordered pair of particles is evaluated exactly once on the whole machine.
 struct N3Args {
     const double *pos;      // exchange buffer
-    const uint64_t *mask;   // [T rows][W] tile-pair mask (all row tiles, not only the owned ones)
+    const uint64_t *mask;   // [TB rows][W] tile-pair mask of the owned row tiles
+    const double *bbox;     // [T][kBoxStride] exact tile bounding boxes (image classification)
     double *slab_i;         // [nchunk][3][P] partial accelerations of the owned rows (row side)
     double *slab_j;         // [NGo][Q][3][64] column-side partial accelerations, Q = (Dmax+1)*4
     unsigned char *flag_j;  // [NGo][Q] 1 = slab_j block written this step
