@@ -75,9 +75,14 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     import torch
-    # torch ships its own ROCm runtime next to the system one libljmd.so links: initialise torch's
-    # first (the order that is known to work), use it only for the contract's synchronize calls
-    torch_gpu = torch.cuda.is_available()
+    # torch bundles its own ROCm 7.0 runtime (libamdhip64.so + libhsa-runtime64.so under torch/lib) next
+    # to the system ROCm 7.2 runtime that libljmd.so and RCCL link, so `torch.cuda.synchronize()` acts on a
+    # HIP runtime that never sees this program's kernels.  Single GPU: it is initialised FIRST (the order
+    # that is known to coexist) and called beside the real synchronisation, as the bench contract words
+    # it.  Multi GPU: torch's runtime is deliberately never initialised -- a second HSA instance per
+    # process next to RCCL's IPC setup is a risk with no benefit -- and the bracket is
+    # gloo barrier + hipStreamSynchronize/hipDeviceSynchronize on the engine's device (Engine.synchronize).
+    torch_gpu = world == 1 and torch.cuda.is_available()
     if torch_gpu:
         torch.cuda.set_device(local_rank)
     import ljmd_amd  # noqa: F401
@@ -115,6 +120,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read()
+    kernel_name = eng.pair_kernel_name()
     force_ms, launches = prof["pair_ms"], prof["launches"]
     integ_ms = prof["drift_ms"] + prof["reduce_ms"]
     eng.profile_enable(False)
@@ -147,7 +153,7 @@ def main() -> None:
             "pair_interactions_per_sec": pairs * steps_per_s,
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "pair_tiles_kernel", "kernel_ms_avg": force_ms, "geometry_prepass_ms_avg": prof["geometry_ms"], "launches_timed": launches,
+                         "kernel": kernel_name, "kernel_ms_avg": force_ms, "geometry_prepass_ms_avg": prof["geometry_ms"], "launches_timed": launches,
                          "flop_per_unordered_pair": FLOP_PER_UNORDERED_PAIR,
                          "hbm_algorithmic_GBps": (48.0 * n / world) / (force_ms * 1e-3) / 1e9 if force_ms > 0 else 0.0,
                          "integrator_ms_avg": integ_ms,
@@ -155,6 +161,14 @@ def main() -> None:
             "energy_check": {"etot_first": float(etot[0]), "etot_last": float(etot[-1]),
                              "rel_drift": float(abs(etot[-1] - etot[0]) / abs(etot[0]))},
         }
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+        # command (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be read from inside the run)
+        pmc = ROOT / "profiles" / "r01_final_pmc_hbm_traffic.json"
+        if world == 1 and n == N_PARTICLES and pmc.exists():
+            k = json.loads(pmc.read_text())["kernels"].get("ljmdk::" + kernel_name + "<3>") or {}
+            if k:
+                line["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = "profiles/r01_final_pmc_hbm_traffic.json"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

@@ -219,6 +219,8 @@ int ljmd_combine_scalars(const ljmd_t *h, const double *partials_by_rank, int32_
  * *launches = number of launches averaged; the counters are reset.
  */
 int ljmd_profile_enable(ljmd_t *h, int32_t on);
+/* Name of the pair-force kernel the next force evaluation will launch (for profile matching). */
+const char *ljmd_pair_kernel_name(const ljmd_t *h);
 int ljmd_profile_read(ljmd_t *h, double *ms_avg /* [4] */, int32_t *launches);
 
 #ifdef __cplusplus

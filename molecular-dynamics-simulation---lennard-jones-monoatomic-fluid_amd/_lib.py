@@ -76,6 +76,7 @@ PROTOTYPES = {
     "ljmd_read_partials": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "ljmd_combine_scalars": (C.c_int, [C.c_void_p, c_double_p, C.c_int32] + [c_double_p] * 4),
     "ljmd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ljmd_pair_kernel_name": (C.c_char_p, [C.c_void_p]),
     "ljmd_profile_read": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
 }
 

@@ -1012,6 +1012,13 @@ int ljmd_synchronize(ljmd_t *h)
 
 // ---- measurement ---------------------------------------------------------------
 
+const char *ljmd_pair_kernel_name(const ljmd_t *h)
+{
+    if (!h) return "";
+    if (!fast_path_ok(h)) return "pair_rows_generic_kernel";
+    return h->use_n3 ? "pair_n3_kernel" : "pair_tiles_kernel";
+}
+
 int ljmd_profile_enable(ljmd_t *h, int32_t on)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_enable: NULL handle");

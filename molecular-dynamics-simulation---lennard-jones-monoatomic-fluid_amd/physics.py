@@ -240,6 +240,9 @@ class Engine:
     def profile_enable(self, on: bool = True) -> None:
         self._ck(self._lib.ljmd_profile_enable(self._h, 1 if on else 0))
 
+    def pair_kernel_name(self) -> str:
+        return self._lib.ljmd_pair_kernel_name(self._h).decode()
+
     def profile_read(self) -> dict:
         """-> {'pair_ms', 'geometry_ms', 'drift_ms', 'reduce_ms', 'launches'} averages per launch"""
         ms = (C.c_double * 4)()
