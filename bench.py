@@ -64,7 +64,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_PARTICLES, help="override the particle count (parity/debug only)")
+    ap.add_argument("--particles", dest="n", type=int, default=N_PARTICLES, help="override the particle count (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -98,9 +98,16 @@ def main() -> None:
 
     n = args.n
     p, r, v = synthetic.make_config(n)
-    eng = Engine(p, device=local_rank, rank=rank, n_ranks=world)
-    distributed.bootstrap_rccl(eng, rank, world)
-    sim = distributed.ShardedSimulation(eng, rank, world)
+    # rehearsal knobs for a box with fewer GPUs than ranks (RCCL refuses two ranks on one device):
+    # LJMD_BENCH_SHARE_DEVICE=1 puts every rank on device 0, LJMD_BENCH_EXCHANGE=host forces the
+    # host-staged exchange.  Never set by the driver; a line produced with them says so in `config`.
+    share = os.environ.get("LJMD_BENCH_SHARE_DEVICE", "0") == "1"
+    eng = Engine(p, device=0 if share else local_rank, rank=rank, n_ranks=world)
+    if os.environ.get("LJMD_BENCH_EXCHANGE", "") == "host" or share:
+        exchange = "host"
+    else:
+        exchange = "rccl" if distributed.try_bootstrap_rccl(eng, rank, world) else "host"
+    sim = distributed.ShardedSimulation(eng, rank, world, exchange=exchange)
 
     def barrier():
         eng.synchronize()                    # hipStreamSynchronize + hipDeviceSynchronize on the engine's device
@@ -148,7 +155,9 @@ def main() -> None:
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"N={n} LJ fluid, rho=0.8, rc=0.49L, dt=0.005, simple-cubic+5% jitter, T=1.0; "
                                    f"all-pairs force + velocity-Verlet step (BASELINE configs[2])",
-                       "particles": n, "sharding": f"rows/{world}" if world > 1 else "single GPU",
+                       "particles": n, "sharding": (f"rows/{world}" + (" (REHEARSAL: all ranks on one device)" if share else "")) if world > 1 else "single GPU",
+                       "exchange": ("RCCL all-gather + reduce-scatter inside libljmd.so" if exchange == "rccl"
+                                    else "HOST-STAGED FALLBACK (RCCL init failed): PCIe + gloo") if world > 1 else "none",
                        "unordered_pairs_per_step": pairs},
             "pair_interactions_per_sec": pairs * steps_per_s,
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,

@@ -1001,6 +1001,18 @@ int ljmd_allgather_positions(ljmd_t *h)
     return LJMD_OK;
 }
 
+int ljmd_memcpy(ljmd_t *h, void *dst, const void *src, int64_t bytes, int32_t kind)
+{
+    if (!h || !dst || !src || bytes < 0 || kind < 1 || kind > 3)
+        return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_memcpy: bad argument");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost
+                                                                           : hipMemcpyDeviceToDevice;
+    LJMD_HIP(h, hipMemcpyAsync(dst, src, (size_t)bytes, k, h->stream));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    return LJMD_OK;
+}
+
 int ljmd_synchronize(ljmd_t *h)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_synchronize: NULL handle");

@@ -35,18 +35,83 @@ def bootstrap_rccl(engine, rank: int, world: int, group=None) -> None:
     engine.comm_init(box[0])
 
 
+def try_bootstrap_rccl(engine, rank: int, world: int, group=None) -> bool:
+    """bootstrap_rccl, but agreed on by all ranks: returns False everywhere if it failed anywhere,
+    so that the caller can switch every rank to the host-staged exchange."""
+    if world == 1:
+        return True
+    import torch
+    import torch.distributed as dist
+    ok = 1
+    try:
+        bootstrap_rccl(engine, rank, world, group)
+    except Exception as exc:  # noqa: BLE001 - any failure means "no RCCL on this node"
+        print(f"[ljmd] rank {rank}: RCCL bootstrap failed: {exc}", flush=True)
+        ok = 0
+    t = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item())
+
+
 class ShardedSimulation:
-    def __init__(self, engine, rank: int, world: int, group=None):
+    """exchange = "rccl": the engine's in-library RCCL collectives (the product path).
+    exchange = "host": SAFETY NET only -- if RCCL cannot be initialised on a node, positions and
+    partial accelerations are staged through pinned host memory and gloo; compute stays on the GPU.
+    Slower (PCIe + TCP per step), reported as such by bench.py."""
+
+    def __init__(self, engine, rank: int, world: int, group=None, exchange: str = "rccl"):
         self.engine = engine
         self.rank, self.world, self.group = rank, world, group
+        self.exchange = exchange
         if world > 1:
             import torch.distributed as dist
             self.dist = dist
+            if exchange == "host":
+                self._init_host_exchange()
 
-    # -- the one data-path collective ---------------------------------------------
+    # -- host-staged fallback ---------------------------------------------------------
+    def _init_host_exchange(self) -> None:
+        import torch
+        ptr, total, off, cnt = self.engine.exchange_buffer()
+        self._x = dict(ptr=ptr, total=total, off=off, cnt=cnt, full=torch.empty(total, dtype=torch.float64))
+        fp, nfp, fr, nfr = self.engine.force_buffers(True)      # the engine must not call RCCL itself
+        self._f = dict(fp=fp, nfp=nfp, fr=fr, nfr=nfr,
+                       part=torch.empty(max(nfp, 1), dtype=torch.float64))
+
+    def _host_allgather(self) -> None:
+        x = self._x
+        own = x["full"][x["off"]:x["off"] + x["cnt"]]
+        self.engine.memcpy(own.data_ptr(), x["ptr"] + 8 * x["off"], 8 * x["cnt"], 2)
+        self.dist.all_gather_into_tensor(x["full"], own, group=self.group)
+        self.engine.memcpy(x["ptr"], x["full"].data_ptr(), 8 * x["total"], 1)
+
+    def _host_reduce_scatter(self) -> None:
+        f = self._f
+        if f["nfr"] == 0:
+            return
+        self.engine.memcpy(f["part"].data_ptr(), f["fp"], 8 * f["nfp"], 2)
+        self.dist.all_reduce(f["part"], group=self.group)
+        blk = f["part"][self.rank * f["nfr"]:(self.rank + 1) * f["nfr"]]
+        self.engine.memcpy(f["fr"], blk.data_ptr(), 8 * f["nfr"], 1)
+
+    # -- the data-path collectives ------------------------------------------------------
     def exchange_positions(self) -> None:
-        if self.world > 1:
+        if self.world == 1:
+            return
+        if self.exchange == "host":
+            self._host_allgather()
+        else:
             self.engine.allgather_positions()
+
+    def _finish(self, kick: bool) -> None:
+        """pair forces + cross-rank force reduction + (kick) for one evaluation."""
+        if self.world > 1 and self.exchange == "host":
+            self.engine.step_forces()
+            self._host_reduce_scatter()
+        if kick:
+            self.engine.step_finish()          # RCCL reduce-scatter happens inside (exchange = "rccl")
+        else:
+            self.engine.forces_partial()
 
     def _gather_partials(self, mine: np.ndarray) -> np.ndarray:
         """mine: [k, PARTIAL_STRIDE] -> [world, k, PARTIAL_STRIDE] (host, tiny)."""
@@ -74,7 +139,7 @@ class ShardedSimulation:
         -> (epot, d_epot, dd_epot) of the t = 0 force evaluation."""
         self.engine.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         self.exchange_positions()      # every rank re-orders its own block at set_state: share the new order
-        self.engine.forces_partial()
+        self._finish(False)
         parts = self._gather_partials(self.engine.read_partials(1))
         e, _k, d, dd = self._combine(parts)
         return e[0], d[0], dd[0]
@@ -84,7 +149,7 @@ class ShardedSimulation:
         for _ in range(nsteps):
             self.engine.step_begin()
             self.exchange_positions()
-            self.engine.step_finish()
+            self._finish(True)
 
     def collect(self, nsteps: int):
         """-> (epot, ekin, d_epot, dd_epot) arrays of the last nsteps enqueued steps."""

@@ -201,6 +201,10 @@ class Engine:
     def allgather_positions(self) -> None:
         self._ck(self._lib.ljmd_allgather_positions(self._h))
 
+    def memcpy(self, dst: int, src: int, nbytes: int, kind: int) -> None:
+        """kind 1 = host->device, 2 = device->host, 3 = device->device (raw addresses)."""
+        self._ck(self._lib.ljmd_memcpy(self._h, dst, src, nbytes, kind))
+
     def synchronize(self) -> None:
         self._ck(self._lib.ljmd_synchronize(self._h))
 

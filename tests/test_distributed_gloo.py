@@ -42,11 +42,27 @@ class OracleShardEngine:
         cnt = 3 * self.S
         dist.all_gather_into_tensor(full, full[self.rank * cnt:(self.rank + 1) * cnt])
 
+    # -- host-staged fallback protocol (raw addresses of numpy buffers) -----------------------
+    def exchange_buffer(self):
+        cnt = 3 * self.S
+        return self.buf.ctypes.data, self.buf.size, self.rank * cnt, cnt
+
+    def force_buffers(self, external):
+        return 0, 0, 0, 0                                   # gather-style engine: nothing to reduce
+
+    def memcpy(self, dst, src, nbytes, kind):
+        import ctypes
+        ctypes.memmove(dst, src, nbytes)
+
+    def step_forces(self):
+        pass
+
     def comm_unique_id(self):
         return b"fake-rccl-id".ljust(128, b"\0")
 
     def comm_init(self, uid):
         assert uid == self.comm_unique_id()
+        assert not getattr(self, "comm_ready", False), "communicator initialised twice"
         self.comm_ready = True
 
     def set_state(self, rx, ry, rz, vx, vy, vz):
@@ -107,7 +123,7 @@ class OracleShardEngine:
                 24.0 * (26.0 * s12 - 7.0 * s6) + tdd)
 
 
-def _worker(rank, world, port, n, nsteps, outdir):
+def _worker(rank, world, port, n, nsteps, outdir, exchange="rccl"):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -119,7 +135,9 @@ def _worker(rank, world, port, n, nsteps, outdir):
         eng = OracleShardEngine(p, rank, world)
         distributed.bootstrap_rccl(eng, rank, world)
         assert eng.comm_ready
-        sim = distributed.ShardedSimulation(eng, rank, world)
+        eng.comm_ready = False
+        assert distributed.try_bootstrap_rccl(eng, rank, world)
+        sim = distributed.ShardedSimulation(eng, rank, world, exchange=exchange)
         e0, d0, dd0 = sim.start(r, v)
         e, k, d, dd = sim.run(nsteps)
         np.savez(Path(outdir) / f"rank{rank}.npz", t0=np.array([e0, d0, dd0]), sc=np.stack([e, k, d, dd], axis=1),
@@ -134,14 +152,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sharded_run_matches_single_process_oracle(tmp_path, oracle, world):
+@pytest.mark.parametrize("world,exchange", [(2, "rccl"), (2, "host")])
+def test_sharded_run_matches_single_process_oracle(tmp_path, oracle, world, exchange):
     import torch.multiprocessing as mp
     from ljmd_amd import synthetic
     n, nsteps = 432, 12
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nsteps, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nsteps, str(tmp_path), exchange))
+             for r in range(world)]
     for p_ in procs:
         p_.start()
     for p_ in procs:

@@ -135,3 +135,34 @@ def test_rccl_communicator_single_rank():
         ref.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         assert ref.compute_forces() == e0
         assert np.array_equal(np.stack(sc), np.stack(ref.verlet_steps(5)))
+
+
+def test_bench_two_processes_host_staged_exchange(tmp_path):
+    """bench.py end to end with TWO processes (torch.distributed.run, gloo control plane) sharing this
+    box's single GPU; the exchange is the host-staged safety net because RCCL refuses two ranks on one
+    device.  Checks the multi-process control flow of the very script the driver launches, and that the
+    2-rank trajectory equals the 1-rank one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, LJMD_BENCH_SHARE_DEVICE="1", LJMD_BENCH_EXCHANGE="host")
+    with __import__("socket").socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "4", "--warmup", "1", "--particles", "32768", "--no-cpu-baseline"]
+    out2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+                           "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    line2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.startswith("{")][-1])
+    out1 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1"] + common, capture_output=True,
+                          text=True, timeout=600)
+    assert out1.returncode == 0, out1.stderr[-2000:]
+    line1 = json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line2["n_gpus"] == 2 and "HOST-STAGED" in line2["config"]["exchange"]
+    for key in ("etot_first", "etot_last"):
+        a, b = line2["energy_check"][key], line1["energy_check"][key]
+        assert abs(a - b) <= 1e-11 * abs(b), (key, a, b)
+    assert line2["value"] > 0 and line2["roofline"]["kernel"] == "pair_n3_kernel"
