@@ -47,7 +47,10 @@ typedef enum ljmd_status {
 
 /* precision_mode for ljmd_create */
 #define LJMD_PRECISION_FP64 0       /* all arithmetic fp64 (BASELINE configs 1-4)            */
-#define LJMD_PRECISION_FP32_FORCE 1 /* fp32 pair arithmetic, fp64 accumulation + integrator  */
+#define LJMD_PRECISION_FP32_FORCE 1 /* mixed: pairs of tiles farther apart than r_split (env
+                                       LJMD_FP32_SPLIT, default 5 sigma; 0 = all but the own row group) in
+                                       fp32 tile-relative arithmetic, nearer pairs in fp64; fp64 accumulation
+                                       and integrator.  Needs n >= 16384.  BASELINE config 5.             */
 
 /* Which state array: argument of ljmd_device_ptr / selectors of get_state. */
 enum { LJMD_R = 0, LJMD_RU = 1, LJMD_V = 2, LJMD_A = 3 };

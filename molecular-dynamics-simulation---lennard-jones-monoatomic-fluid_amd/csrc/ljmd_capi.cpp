@@ -96,6 +96,11 @@ struct ljmd {
     int NG = 0, NGo = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
     double *d_slab_j = nullptr;
     unsigned char *d_flag_j = nullptr;
+    // mixed precision (mode = LJMD_PRECISION_FP32_FORCE): far tile pairs in fp32
+    uint64_t *d_mask_far = nullptr;
+    double *d_slab_j2 = nullptr;
+    unsigned char *d_flag_j2 = nullptr;
+    double r_split = 5.0;             // LJMD_FP32_SPLIT: boxes closer than this stay fp64
     // reduced raw accelerations: fpart [G or 1][3][P]; frecv [3][P] = reduce-scatter result (G > 1, Newton-3)
     double *d_fpart = nullptr, *d_frecv = nullptr;
     bool forces_pending = false;      // pair kernel + slab reduction enqueued, kick not yet
@@ -178,6 +183,8 @@ GeometryArgs geometry_args(ljmd_t *h)
     a.W = h->W;
     a.L = h->L;
     a.rc2_skin = h->rc2 * (1.0 + 1e-10);
+    a.mask_far = h->d_mask_far;       // NULL unless mixed precision
+    a.rsplit2 = h->r_split * h->r_split;
     return a;
 }
 
@@ -235,6 +242,8 @@ ReduceArgs reduce_args(ljmd_t *h, int nslab, bool n3)
     a.slab = h->d_slab;
     a.slab_j = n3 ? h->d_slab_j : nullptr;
     a.flag_j = n3 ? h->d_flag_j : nullptr;
+    a.slab_j2 = (n3 && h->mode == LJMD_PRECISION_FP32_FORCE) ? h->d_slab_j2 : nullptr;
+    a.flag_j2 = (n3 && h->mode == LJMD_PRECISION_FP32_FORCE) ? h->d_flag_j2 : nullptr;
     a.fpart = h->d_fpart;
     a.nslab = nslab;
     a.P = h->P;
@@ -336,16 +345,29 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
     int nslab, n_wg;
     bool n3 = false;
     if (fast) {
-        const GeometryArgs ga = geometry_args(h);
+        GeometryArgs ga = geometry_args(h);
+        if (!h->use_n3) ga.mask_far = nullptr;
         LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
         LJMD_HIP(h, launch_tile_mask(ga, h->stream));
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
             const dim3 grid((h->NGo + kWavesPerBlock - 1) / kWavesPerBlock, h->nslab_n);
-            LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->n3_waves, h->stream));
+            LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->n3_waves, h->stream));   // all pairs, or the NEAR ones
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y;
             n3 = true;
+            if (h->mode == LJMD_PRECISION_FP32_FORCE) {
+                // far pass in fp32: its own row-side slices, column-side slab and workgroup partials
+                N3Args fa = n3_args(h);
+                fa.mask = h->d_mask_far;
+                fa.slab_i = h->d_slab + (size_t)h->nslab_n * 3 * h->P;
+                fa.slab_j = h->d_slab_j2;
+                fa.flag_j = h->d_flag_j2;
+                fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
+                LJMD_HIP(h, launch_pair_n3_f32(fa, grid, h->stream));
+                nslab *= 2;
+                n_wg *= 2;
+            }
         } else {
             const dim3 grid(h->TB / kWavesPerBlock, h->nslab_t);
             LJMD_HIP(h, launch_pair_tiles(pair_args(h, true), grid, h->stream));
@@ -457,7 +479,7 @@ void release(ljmd_t *h)
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv,
-                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2};
+                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -517,7 +539,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     if (rc >= 0.5 * box_length)
         return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: rc must be < L/2 (minimum image convention)");
     if (!(dt > 0.0)) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: dt must be > 0");
-    if (precision_mode != LJMD_PRECISION_FP64)
+    if (precision_mode != LJMD_PRECISION_FP64 && precision_mode != LJMD_PRECISION_FP32_FORCE)
         return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: precision_mode %d not available", precision_mode);
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
         return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create: bad rank %d of %d", rank, n_ranks);
@@ -616,9 +638,20 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->dchunk = (h->Dmax + 1 + ns - 1) / ns;
         h->nslab_n = (h->Dmax + 1 + h->dchunk - 1) / h->dchunk;
     }
-    const int nslab_max = std::max(std::max(h->nslab_g, h->nslab_t), h->use_n3 ? h->nslab_n : 1);
+    const bool mixed = precision_mode == LJMD_PRECISION_FP32_FORCE;
+    if (mixed && !h->use_n3) {
+        delete h;
+        return fail(nullptr, LJMD_ERR_INVALID_ARG,
+                    "ljmd_create: LJMD_PRECISION_FP32_FORCE needs the Newton-3 path (n >= %d)",
+                    env_int("LJMD_N3_MIN_N", 16384));
+    }
+    {
+        const char *rs = std::getenv("LJMD_FP32_SPLIT");
+        if (rs && *rs) h->r_split = std::max(0.0, std::atof(rs));
+    }
+    const int nslab_max = std::max(std::max(h->nslab_g, h->nslab_t), h->use_n3 ? h->nslab_n * (mixed ? 2 : 1) : 1);
     const int n_wg_max = std::max(row_blocks * std::max(h->nslab_g, h->nslab_t),
-                                  ((h->NGo + kWavesPerBlock - 1) / kWavesPerBlock) * h->nslab_n);
+                                  ((h->NGo + kWavesPerBlock - 1) / kWavesPerBlock) * h->nslab_n * (mixed ? 2 : 1));
     h->n_ke = row_blocks;
     h->h_perm.resize(h->P);
     for (int i = 0; i < h->P; ++i) h->h_perm[i] = i;
@@ -638,6 +671,12 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
             LJMD_HIP(h, hipMalloc(&h->d_slab_j, (size_t)h->NGo * h->Q * 3 * kTile * sizeof(double)));
             LJMD_HIP(h, hipMalloc(&h->d_flag_j, (size_t)h->NGo * h->Q));
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, (size_t)h->NGo * h->Q, h->stream));
+        }
+        if (mixed) {
+            LJMD_HIP(h, hipMalloc(&h->d_mask_far, (size_t)h->TB * h->W * sizeof(uint64_t)));
+            LJMD_HIP(h, hipMalloc(&h->d_slab_j2, (size_t)h->NGo * h->Q * 3 * kTile * sizeof(double)));
+            LJMD_HIP(h, hipMalloc(&h->d_flag_j2, (size_t)h->NGo * h->Q));
+            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j2, 0, (size_t)h->NGo * h->Q, h->stream));
         }
         LJMD_HIP(h, hipMalloc(&h->d_fpart, P3 * (needs_force_exchange(h) ? h->G : 1)));
         if (needs_force_exchange(h)) LJMD_HIP(h, hipMalloc(&h->d_frecv, P3));
@@ -1028,6 +1067,7 @@ const char *ljmd_pair_kernel_name(const ljmd_t *h)
 {
     if (!h) return "";
     if (!fast_path_ok(h)) return "pair_rows_generic_kernel";
+    if (h->use_n3 && h->mode == LJMD_PRECISION_FP32_FORCE) return "pair_n3_f32_kernel";
     return h->use_n3 ? "pair_n3_kernel" : "pair_tiles_kernel";
 }
 

@@ -76,6 +76,8 @@ struct ReduceArgs {
     const double *slab;     // row side [nslab][3][P]
     const double *slab_j;   // column side (Newton-3) or NULL
     const unsigned char *flag_j;
+    const double *slab_j2;  // second column-side set (fp32 far pass of the mixed-precision mode) or NULL
+    const unsigned char *flag_j2;
     double *fpart;
     int nslab, P, G, rank, TB, NG, NGo, Dmax, Q;
 };
@@ -94,8 +96,11 @@ struct GeometryArgs {
     const double *pos;      // exchange buffer
     double *bbox;           // [T][kBoxStride]
     uint64_t *mask;         // [TB][W]
+    uint64_t *mask_far;     // mixed precision only (else NULL): [TB][W] tile pairs evaluated in fp32;
+                            // `mask` then holds only the NEAR pairs (box distance <= r_split, or same row group)
     int P, G, rank, TB, T, W;
     double L, rc2_skin;     // rc^2 * (1 + 1e-10): skip only when provably outside
+    double rsplit2;         // r_split^2
 };
 
 struct SortArgs {
@@ -109,6 +114,7 @@ struct SortArgs {
 hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s);
+hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);
 hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);

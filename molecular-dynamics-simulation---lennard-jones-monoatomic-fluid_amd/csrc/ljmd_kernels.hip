@@ -491,6 +491,196 @@ __global__ __launch_bounds__(kBlock, MIN_WAVES) void pair_n3_kernel(N3Args a)
     }
 }
 
+// ===========================================================================
+// K2 far pass of the mixed-precision mode (LJMD_PRECISION_FP32_FORCE): the same Newton-3 rotation
+// scheme, pair arithmetic in fp32.  Only tile pairs whose boxes are farther apart than r_split
+// come here (mask_far); everything closer -- where the forces are large -- stays in the fp64 kernel.
+//   * coordinates are tile-relative: offset = (float)(x - tile centre); the centre difference of a
+//     (row tile, column tile) pair, minus the periodic image shift when it is uniform, is formed in
+//     fp64, rounded once to fp32 and folded into the row offsets, so a pair costs 3 fp32 subtractions;
+//   * 1/r^2 = v_rcp_f32 (1 ulp); per column tile the partial accelerations and the two energy sums
+//     are accumulated in fp32 (<= 256 terms) and then added to fp64 accumulators;
+//   * relative error of a far pair's force ~1e-7, absolute < 1e-11 (|f| < 24 r_split^-7).
+// ===========================================================================
+__device__ __forceinline__ float dpp_rotate_f32(float v)
+{
+    const int i = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x13C, 0xF, 0xF, false);
+    return __int_as_float(i);
+}
+
+template <bool UNIFORM>
+__device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float xj, float yj, float zj,
+                                            float Lf, float invLf, float rc2f,
+                                            float &ax, float &ay, float &az, float &jx, float &jy, float &jz,
+                                            float &s12, float &s6)
+{
+    float dx = xi - xj, dy = yi - yj, dz = zi - zj;
+    if constexpr (!UNIFORM) {
+        dx = fmaf(-Lf, __builtin_rintf(dx * invLf), dx);
+        dy = fmaf(-Lf, __builtin_rintf(dy * invLf), dy);
+        dz = fmaf(-Lf, __builtin_rintf(dz * invLf), dz);
+    }
+    const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    if (r2 < rc2f) {
+        const float u = __builtin_amdgcn_rcpf(r2);
+        const float u3 = u * u * u;
+        const float u6 = u3 * u3;
+        s12 += u6;
+        s6 += u3;
+        const float g = fmaf(2.0f, u6, -u3) * u;
+        ax = fmaf(g, dx, ax);
+        ay = fmaf(g, dy, ay);
+        az = fmaf(g, dz, az);
+        jx = fmaf(-g, dx, jx);
+        jy = fmaf(-g, dy, jy);
+        jz = fmaf(-g, dz, jz);
+    }
+}
+
+template <bool UNIFORM, bool MASKED>
+__device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], const float (&py)[kRowTiles],
+                                                const float (&pz)[kRowTiles], float (&fx)[kRowTiles],
+                                                float (&fy)[kRowTiles], float (&fz)[kRowTiles],
+                                                float xj, float yj, float zj, unsigned mb,
+                                                float Lf, float invLf, float rc2f,
+                                                float &jx, float &jy, float &jz, float &s12, float &s6)
+{
+    for (int s = 0; s < kTile; ++s) {
+#pragma unroll
+        for (int k = 0; k < kRowTiles; ++k)
+            if (!MASKED || ((mb >> k) & 1u))
+                pair_n3_f32<UNIFORM>(px[k], py[k], pz[k], xj, yj, zj, Lf, invLf, rc2f, fx[k], fy[k], fz[k],
+                                     jx, jy, jz, s12, s6);
+        xj = dpp_rotate_f32(xj); yj = dpp_rotate_f32(yj); zj = dpp_rotate_f32(zj);
+        jx = dpp_rotate_f32(jx); jy = dpp_rotate_f32(jy); jz = dpp_rotate_f32(jz);
+    }
+}
+
+__global__ __launch_bounds__(kBlock, 4) void pair_n3_f32_kernel(N3Args a)
+{
+    __shared__ double red[2 * kWavesPerBlock];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Al = blockIdx.x * kWavesPerBlock + wave;
+    const bool active = Al < a.NGo;
+    const int A = a.rank * a.NGo + Al;
+    const size_t P = a.P;
+    const double *own = a.pos + (size_t)a.rank * 3 * P;
+    const float Lf = (float)a.L, invLf = (float)a.invL, rc2f = (float)a.rc2;
+
+    // row tiles: centre (from the exact boxes), fp32 offsets, fp64 accumulators
+    double cx[kRowTiles], cy[kRowTiles], cz[kRowTiles];
+    float ox[kRowTiles], oy[kRowTiles], oz[kRowTiles];
+    double ax[kRowTiles], ay[kRowTiles], az[kRowTiles];
+    double glo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+    double ghi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+    double s12 = 0.0, s6 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kRowTiles; ++k) {
+        const int tl = active ? kRowTiles * Al + k : 0;
+        const double *bb = a.bbox + (size_t)(a.rank * a.TB + tl) * kBoxStride;
+        cx[k] = 0.5 * (bb[0] + bb[3]);
+        cy[k] = 0.5 * (bb[1] + bb[4]);
+        cz[k] = 0.5 * (bb[2] + bb[5]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            glo[q] = fmin(glo[q], bb[q]);
+            ghi[q] = fmax(ghi[q], bb[3 + q]);
+        }
+        const size_t slot = (size_t)tl * kTile + lane;
+        ox[k] = (float)(own[slot] - cx[k]);
+        oy[k] = (float)(own[P + slot] - cy[k]);
+        oz[k] = (float)(own[2 * P + slot] - cz[k]);
+        ax[k] = ay[k] = az[k] = 0.0;
+    }
+
+    const int d0 = blockIdx.y * a.dchunk;
+    const int d1 = active ? min(d0 + a.dchunk, a.Dmax + 1) : d0;
+    for (int d = d0; d < d1; ++d) {
+        int B = A + d;
+        if (B >= a.NG) B -= a.NG;
+        const bool own_pair = (d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B);
+        for (int l = 0; l < kRowTiles; ++l) {
+            const int c = kRowTiles * B + l;
+            const size_t blk = (size_t)Al * a.Q + (size_t)d * kRowTiles + l;
+            unsigned mb = 0;
+            if (own_pair && d != 0) {                      // the diagonal group is always a NEAR (fp64) pair
+#pragma unroll
+                for (int k = 0; k < kRowTiles; ++k) {
+                    const uint64_t w = a.mask[(size_t)(kRowTiles * Al + k) * a.W + (c >> 6)];
+                    mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
+                }
+            }
+            if (mb == 0) {
+                if (lane == 0) a.flag_j[blk] = 0;
+                continue;
+            }
+            const double *cbx = a.bbox + (size_t)c * kBoxStride;
+            const double ccx = 0.5 * (cbx[0] + cbx[3]), ccy = 0.5 * (cbx[1] + cbx[4]), ccz = 0.5 * (cbx[2] + cbx[5]);
+            double sx = 0.0, sy = 0.0, sz = 0.0;
+            const bool ux = uniform_image(glo[0] - cbx[3], ghi[0] - cbx[0], a.L, a.invL, sx);
+            const bool uy = uniform_image(glo[1] - cbx[4], ghi[1] - cbx[1], a.L, a.invL, sy);
+            const bool uz = uniform_image(glo[2] - cbx[5], ghi[2] - cbx[2], a.L, a.invL, sz);
+            const bool uni = __builtin_amdgcn_readfirstlane((int)(ux && uy && uz)) != 0;
+            if (!uni) sx = sy = sz = 0.0;
+
+            const int gj = (a.G == 1) ? 0 : c / a.TB;
+            const double *cb = a.pos + (size_t)gj * 3 * P + (size_t)(c - gj * a.TB) * kTile + lane;
+            const float xj = (float)(cb[0] - ccx), yj = (float)(cb[P] - ccy), zj = (float)(cb[2 * P] - ccz);
+
+            // row offsets in the column tile's frame: (x_i - c_k) + ((c_k - c_c) - shift)
+            float px[kRowTiles], py[kRowTiles], pz[kRowTiles], fx[kRowTiles], fy[kRowTiles], fz[kRowTiles];
+#pragma unroll
+            for (int k = 0; k < kRowTiles; ++k) {
+                px[k] = ox[k] + (float)((cx[k] - ccx) - sx);
+                py[k] = oy[k] + (float)((cy[k] - ccy) - sy);
+                pz[k] = oz[k] + (float)((cz[k] - ccz) - sz);
+                fx[k] = fy[k] = fz[k] = 0.0f;
+            }
+            float jx = 0.0f, jy = 0.0f, jz = 0.0f, t12 = 0.0f, t6 = 0.0f;
+            if (mb == 15u && uni)
+                column_loop_f32<true, false>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
+            else if (mb == 15u)
+                column_loop_f32<false, false>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
+            else if (uni)
+                column_loop_f32<true, true>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
+            else
+                column_loop_f32<false, true>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
+#pragma unroll
+            for (int k = 0; k < kRowTiles; ++k) {
+                ax[k] += (double)fx[k];
+                ay[k] += (double)fy[k];
+                az[k] += (double)fz[k];
+            }
+            s12 += (double)t12;
+            s6 += (double)t6;
+            double *o = a.slab_j + blk * (3 * kTile) + lane;
+            o[0] = (double)jx;
+            o[kTile] = (double)jy;
+            o[2 * kTile] = (double)jz;
+            if (lane == 0) a.flag_j[blk] = 1;
+        }
+    }
+
+    if (active) {
+        double *si = a.slab_i + (size_t)blockIdx.y * 3 * P;
+#pragma unroll
+        for (int k = 0; k < kRowTiles; ++k) {
+            const size_t slot = (size_t)(kRowTiles * Al + k) * kTile + lane;
+            si[slot] = ax[k];
+            si[P + slot] = ay[k];
+            si[2 * P + slot] = az[k];
+        }
+    }
+    double v[2] = {s12, s6};
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        double *w = a.wg_part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        w[0] = v[0];
+        w[1] = v[1];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Geometry pre-pass 1: exact axis-aligned bounding box of every 64-slot tile of the
 // exchange buffer (NaN padding ignored).  One wave per tile; reads 24 N bytes.
@@ -539,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
     if (Il >= a.TB) return;
     const int I = a.rank * a.TB + Il;
     const int J = w * 64 + lane;
-    bool keep = false;
+    bool keep = false, far = false;
     if (J < a.T) {
         const double *bi = a.bbox + (size_t)I * kBoxStride;
         const double *bj = a.bbox + (size_t)J * kBoxStride;
@@ -550,6 +740,16 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
             d2 += g * g;
         }
         keep = !(d2 > a.rc2_skin) || (J == I);
+        if (a.mask_far) {
+            // mixed precision: fp64 for boxes closer than r_split and inside the own row group, fp32 beyond
+            const bool near = (d2 <= a.rsplit2) || (J / kRowTiles == I / kRowTiles);
+            far = keep && !near;
+            keep = keep && near;
+        }
+    }
+    if (a.mask_far) {
+        const uint64_t far_word = __ballot(far);
+        if (lane == 0) a.mask_far[(size_t)Il * a.W + w] = far_word;
     }
     const uint64_t word = __ballot(keep);
     if (lane == 0) a.mask[(size_t)Il * a.W + w] = word;
@@ -612,6 +812,12 @@ __global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
             const size_t blk = (size_t)Al * a.Q + (size_t)d * kRowTiles + l;
             if (a.flag_j[blk]) {
                 const double *b = a.slab_j + blk * (3 * kTile) + lane;
+                s[0] += b[0];
+                s[1] += b[kTile];
+                s[2] += b[2 * kTile];
+            }
+            if (a.slab_j2 && a.flag_j2[blk]) {
+                const double *b = a.slab_j2 + blk * (3 * kTile) + lane;
                 s[0] += b[0];
                 s[1] += b[kTile];
                 s[2] += b[2 * kTile];
@@ -739,6 +945,12 @@ hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t
         hipLaunchKernelGGL(pair_n3_kernel<4>, grid, dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(pair_n3_kernel<5>, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(pair_n3_f32_kernel, grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

@@ -325,6 +325,39 @@ def test_resort_keeps_particle_identity(golden):
     assert np.max(np.abs(np.stack(fin["ru"]) - r0)) < 1.0    # nobody moved a sigma in 35 steps
 
 
+@pytest.mark.parametrize("split", ["5", "0"])
+def test_mixed_precision_mode_accuracy_and_drift(split, monkeypatch):
+    """BASELINE config 5 (fp32 pair arithmetic for far tile pairs, fp64 near pairs + accumulation +
+    integrator) against the fp64 engine on the same start: forces to fp32-level accuracy, the
+    200-step total-energy series within 1e-7 relative of the fp64 one (the reference's own energy
+    wander over such a run is ~1e-4, SURVEY fact #4)."""
+    from ljmd_amd import _lib
+    monkeypatch.setenv("LJMD_FP32_SPLIT", split)
+    n = 32768
+    p, r, v = synthetic.make_config(n, seed=21)
+    out = {}
+    for mode in (_lib.PRECISION_FP64, _lib.PRECISION_FP32_FORCE):
+        with Engine(p, precision_mode=mode) as eng:
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            sc0 = eng.compute_forces()
+            a0 = np.stack(eng.get_state(("a",))["a"])
+            e, k, d, dd = eng.verlet_steps(200)
+            out[mode] = (np.array(sc0), a0, e + k, np.stack(eng.get_state(("v",))["v"]))
+    f64, mix = out[_lib.PRECISION_FP64], out[_lib.PRECISION_FP32_FORCE]
+    # epot, d_epot, dd_epot; d_epot = 24 (S6 - 2 S12) cancels to ~1/10 of its terms, hence the looser all-fp32 bound
+    assert np.max(np.abs(mix[0] - f64[0]) / np.abs(f64[0])) < (2e-7 if split == "5" else 5e-6)
+    amax = np.abs(f64[1]).max()
+    # all-fp32 (split 0): tile-relative fp32 coordinates give ~3e-6 relative error on the close, large forces
+    assert np.abs(mix[1] - f64[1]).max() < (2e-7 if split == "5" else 2e-5) * amax
+    if split == "5":
+        assert np.abs(mix[1] - f64[1]).max() < 1e-8 * amax                    # near pairs (the big forces) stay fp64
+    assert np.max(np.abs(mix[2] - f64[2]) / np.abs(f64[2])) < 1e-7            # Etot(t), 200 steps
+    # Newton 3 holds per pair, but row and column sides round their fp32 partial sums differently
+    assert np.abs(mix[3].sum(axis=1)).max() < (1e-6 if split == "5" else 5e-3)
+    with pytest.raises(ljmd_amd.LjmdError):
+        Engine(init_params(4096, 17.2, 0.005, 8.0), precision_mode=_lib.PRECISION_FP32_FORCE)   # n too small
+
+
 def test_argument_guards_and_sequence_errors():
     with pytest.raises(ljmd_amd.LjmdError) as ei:
         Engine(ljmd_amd.SimParams(n=10, box_length=10.0, dt=0.005, rc=5.0))      # rc >= L/2

@@ -23,7 +23,7 @@ for rnd in range(int(os.environ.get("PROBE_ROUNDS", "2"))):
             k, val = kv.split("=")
             os.environ[k] = val
             keys.append(k)
-        with Engine(p) as eng:
+        with Engine(p, precision_mode=int(os.environ.get('PROBE_MODE', '0'))) as eng:
             eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
             eng.compute_forces()
             eng.verlet_steps(2)
