@@ -75,6 +75,22 @@ def test_thin_fortran_driver_error_convention(tmp_path):
     assert not (tmp_path / "outputs" / "one_run").exists()
 
 
+def test_thin_fortran_pipeline_init_then_production(tmp_path):
+    """Our two thin drivers back to back (the reference's run_all.sh sequence: init -> production):
+    md_initial_config_gpu must reproduce the reference's rv_init.dat (FCC + ran3 velocities + rescale +
+    100 warm-up steps on the GPU), and the production driver fed with OUR rv_init.dat must reproduce
+    the reference's energies file."""
+    src = _workdir(tmp_path, "oi100")
+    (tmp_path / "outputs" / "rv_init.dat").unlink()
+    subprocess.run([str(PKG / "bin" / "md_initial_config_gpu")], cwd=tmp_path, check=True, timeout=120)
+    r1, v1 = io_formats.read_rv_init(tmp_path / "outputs" / "rv_init.dat", 108)
+    r2, v2 = io_formats.read_rv_init(src / "rv_init.dat", 108)
+    assert (tmp_path / "outputs" / "rv_init.dat").stat().st_size == 5200
+    assert np.abs(r1 - r2).max() < 1e-10 and np.abs(v1 - v2).max() < 1e-9
+    subprocess.run([str(PKG / "bin" / "md_simulation_gpu")], cwd=tmp_path, check=True, timeout=120)
+    _compare_run(tmp_path, src, 9)
+
+
 @pytest.mark.skipif(not (REF / "md_simulation_program_gpu").exists(),
                     reason="drop-in binary is built only where /root/reference exists")
 def test_reference_main_program_with_gpu_shim(tmp_path):
