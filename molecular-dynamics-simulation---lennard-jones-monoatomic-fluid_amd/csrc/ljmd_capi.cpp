@@ -1086,12 +1086,23 @@ int ljmd_profile_read(ljmd_t *h, double *ms_avg, int32_t *launches)
     LJMD_HIP(h, hipStreamSynchronize(h->stream));
     double acc[4] = {0, 0, 0, 0};  // pair kernel, geometry pre-pass, drift/kick, reduce+finalize
     const int from[4] = {2, 1, 0, 3}, to[4] = {3, 2, 1, 4};
-    for (size_t k = 0; k < h->ev_used; ++k)
-        for (int c = 0; c < 4; ++c) {
-            float ms = 0.f;
-            LJMD_HIP(h, hipEventElapsedTime(&ms, h->ev_pool[k].e[from[c]], h->ev_pool[k].e[to[c]]));
-            acc[c] += ms;
+    size_t complete = 0;
+    for (size_t k = 0; k < h->ev_used; ++k) {
+        double one[4];
+        bool ok = true;
+        for (int c = 0; c < 4 && ok; ++c) {
+            float ms = 0.f;   // a set whose step was only half enqueued has unrecorded events: skip it
+            ok = hipEventElapsedTime(&ms, h->ev_pool[k].e[from[c]], h->ev_pool[k].e[to[c]]) == hipSuccess;
+            one[c] = ms;
         }
+        if (!ok) {
+            (void)hipGetLastError();
+            continue;
+        }
+        for (int c = 0; c < 4; ++c) acc[c] += one[c];
+        ++complete;
+    }
+    h->ev_used = complete;
     const double cnt = h->ev_used ? (double)h->ev_used : 1.0;
     if (ms_avg)
         for (int c = 0; c < 4; ++c) ms_avg[c] = acc[c] / cnt;

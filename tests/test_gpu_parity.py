@@ -83,6 +83,27 @@ def test_newton3_short_trajectory(golden, monkeypatch):
         assert np.max(np.abs(a - b) / np.abs(b)) <= REL_TRAJ, nm
 
 
+def test_production_kernel_configuration_vs_oracle_n32768(oracle):
+    """The default kernel set exactly as bench.py runs it (k-d ordering, tile-pair skipping -- 512 tiles,
+    rc = 16.9 in a 34.5 box, so the mask really drops tile pairs --, uniform-image variants, Newton-3,
+    Halley reciprocal) against the pinned C oracle on EVERY particle; the oracle takes ~5 s here."""
+    n = 32768
+    p, r, v = synthetic.make_config(n, seed=77)
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    with Engine(p) as eng:
+        assert eng.pair_kernel_name() == "pair_n3_kernel" or True      # name is final only after set_state
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert eng.pair_kernel_name() == "pair_n3_kernel"
+        e, d, dd = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+    a_o = np.stack([ax, ay, az])
+    # 2.7e8 in-cutoff terms: the oracle's own sequential running sums carry ~sqrt(n_terms) * 1e-16 = 2e-12
+    # of rounding noise, so the single-call scalar bound of the N <= 4096 fixtures (1e-13) scales to 1e-12
+    assert rel(e, e_o) <= 1e-12 and rel(d, d_o) <= 1e-12 and rel(dd, dd_o) <= 1e-12
+    assert np.abs(a - a_o).max() <= REL_ACCEL * np.abs(a_o).max()
+
+
 def test_force_fcc108_known_answer(golden, oracle):
     g = golden("force_fcc108")
     L = float(g["L"])
