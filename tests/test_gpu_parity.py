@@ -104,6 +104,28 @@ def test_production_kernel_configuration_vs_oracle_n32768(oracle):
     assert np.abs(a - a_o).max() <= REL_ACCEL * np.abs(a_o).max()
 
 
+@pytest.mark.parametrize("n,rc_over_L,n3", [(4096, 0.15, True), (4096, 0.15, False), (32768, 0.08, True), (2500, 0.30, True)])
+def test_short_cutoff_most_tile_pairs_skipped(oracle, n, rc_over_L, n3, monkeypatch):
+    """rc well below L/2 (allowed by the reference: 0 < rc_over_L <= 0.5): most tile pairs are masked
+    out, whole offset ranges of the Newton-3 kernel see no work.  Against the pinned oracle."""
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1" if n3 else "100000000")
+    p, r, v = synthetic.make_config(n, seed=31, rc_over_L=rc_over_L)
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    st = {"rx": r[0].copy(), "ry": r[1].copy(), "rz": r[2].copy(), "ux": r[0].copy(), "uy": r[1].copy(),
+          "uz": r[2].copy(), "vx": v[0].copy(), "vy": v[1].copy(), "vz": v[2].copy(), "ax": ax.copy(), "ay": ay.copy(), "az": az.copy()}
+    nsteps = 12 if n <= 4096 else 2
+    sc_o = oracle.run_steps(po, nsteps, st)
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e, d, dd = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+        sc = np.stack(eng.verlet_steps(nsteps), axis=1)
+    assert rel(e, e_o) <= 1e-12 and rel(d, d_o) <= 1e-12 and rel(dd, dd_o) <= 1e-12
+    assert np.abs(a - np.stack([ax, ay, az])).max() <= REL_ACCEL * np.abs(ax).max()
+    assert np.max(np.abs(sc - sc_o) / np.abs(sc_o)) < 1e-10
+
+
 def test_force_fcc108_known_answer(golden, oracle):
     g = golden("force_fcc108")
     L = float(g["L"])
