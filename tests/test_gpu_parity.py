@@ -401,6 +401,35 @@ def test_mixed_precision_mode_accuracy_and_drift(split, monkeypatch):
         Engine(init_params(4096, 17.2, 0.005, 8.0), precision_mode=_lib.PRECISION_FP32_FORCE)   # n too small
 
 
+def test_one_million_particles_single_gpu_indexing():
+    """BASELINE config 4 size (N = 1 048 576 = 4 * 64^3, FCC + jitter) on ONE GPU: the column-side slab is
+    52 GB here (sized for 288 GB of HBM) and block offsets exceed 2^32 -- an indexing test.  Properties:
+    total force = 0 (Newton 3), sampled rows against a direct numpy evaluation, two steps keep Etot."""
+    n = 1048576
+    p, r, v = synthetic.make_config(n, lattice="fcc")
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e0, d0, dd0 = eng.compute_forces()
+        k0 = eng.kinetic_energy()
+        a = np.stack(eng.get_state(("a",))["a"])
+        e, k, d, dd = eng.verlet_steps(2)
+    amax = np.abs(a).max()
+    assert np.isfinite(e0) and np.abs(a.sum(axis=1)).max() < 1e-9 * amax * np.sqrt(n)
+    L = p.box_length
+    rows = np.random.Generator(np.random.PCG64(9)).choice(n, size=6, replace=False)
+    for i in rows:
+        dvec = r[:, i:i + 1] - r
+        dvec -= L * np.round(dvec / L)
+        r2_ = (dvec * dvec).sum(axis=0)
+        m = (r2_ < p.rc_square) & (np.arange(n) != i)
+        u = 1.0 / r2_[m]
+        u3 = u * u * u
+        a_np = 24.0 * (((2.0 * u3 * u3 - u3) * u) * dvec[:, m]).sum(axis=1)
+        assert np.abs(a_np - a[:, i]).max() < 1e-10 * max(np.abs(a_np).max(), 1.0)
+    etot = e + k
+    assert abs(etot[-1] - (e0 + k0)) < 1e-5 * abs(e0 + k0)
+
+
 def test_argument_guards_and_sequence_errors():
     with pytest.raises(ljmd_amd.LjmdError) as ei:
         Engine(ljmd_amd.SimParams(n=10, box_length=10.0, dt=0.005, rc=5.0))      # rc >= L/2
