@@ -82,6 +82,7 @@ struct ljmd {
     bool kd_sort = true;
     std::vector<int> kd_level_nseg;       // segments at level l
     std::vector<size_t> kd_level_off;     // offset of level l's boundaries inside d_kd_offsets
+    std::vector<int> kd_axis;             // split axis of level l: always the longest remaining extent
     int *d_kd_offsets = nullptr;
     unsigned long long *d_kd_keys = nullptr, *d_kd_keys2 = nullptr;   // [P]
 
@@ -294,7 +295,7 @@ int resort(ljmd_t *h, bool with_accel)
                                    h->stream));   // slots S..P-1 (padding) keep their identity in both buffers
         int *cur = h->d_idx, *nxt = h->d_idx2;
         for (size_t l = 0; l < h->kd_level_nseg.size(); ++l) {
-            const double *axis = own_block(h) + (size_t)(l % 3) * h->P;
+            const double *axis = own_block(h) + (size_t)h->kd_axis[l] * h->P;
             LJMD_HIP(h, kd_level(h->d_cub, h->cub_bytes, axis, h->L, h->d_kd_keys, h->d_kd_keys2, cur, nxt, h->S,
                                  h->kd_level_nseg[l], h->d_kd_offsets + h->kd_level_off[l], h->stream));
             std::swap(cur, nxt);
@@ -583,7 +584,8 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->tail_dd = 2.0 * tf * (26.0 / (3.0 * rc6) - 7.0);
     }
     h->rc_allows_fast = rc <= (1.0 - 1e-9) * 0.5 * box_length;
-    h->sort_enabled = env_int("LJMD_SORT", 1) != 0;
+    // below ~16 tiles there is nothing for the tile mask to skip: keep the caller's order
+    h->sort_enabled = env_int("LJMD_SORT", 1) != 0 && n >= env_int("LJMD_SORT_MIN_N", 1024);
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
     h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", 10));
     h->ncell = std::max(1, std::min(1023, (int)std::floor(box_length / 1.2)));
@@ -751,6 +753,28 @@ int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *
     h->positions_compact = finite;
     for (int ax = 0; ax < 3; ++ax)
         if (!(hi[ax] - lo[ax] < 2.4 * h->L)) h->positions_compact = false;
+    {   // k-d split axes: halve the longest remaining extent of the OWN shard at every level, so that a
+        // slab- or column-shaped shard (multi-GPU index ranges) still ends in near-cubic tiles
+        double ext[3];
+        for (int ax = 0; ax < 3; ++ax) {
+            double slo = INFINITY, shi = -INFINITY;
+            const double *sp = src[ax] + (size_t)h->rank * S;
+            for (size_t i = 0; i < S; ++i) {
+                slo = std::min(slo, sp[i]);
+                shi = std::max(shi, sp[i]);
+            }
+            ext[ax] = std::isfinite(shi - slo) ? std::min(shi - slo, h->L) : h->L;
+            if (!(ext[ax] > 0.0)) ext[ax] = 1e-300;
+        }
+        h->kd_axis.assign(h->kd_level_nseg.size(), 0);
+        for (size_t l = 0; l < h->kd_axis.size(); ++l) {
+            int best = 0;
+            for (int ax = 1; ax < 3; ++ax)
+                if (ext[ax] > ext[best] * (1.0 + 1e-9)) best = ax;   // ties -> lowest axis: x, y, z cycling for a cube
+            h->kd_axis[l] = best;
+            ext[best] *= 0.5;
+        }
+    }
     LJMD_HIP(h, hipMemcpyAsync(h->d_pos, h->h_stage, 3 * P * h->G * sizeof(double), hipMemcpyHostToDevice,
                                h->stream));
     // ru <- r (md_simulation_program.f90:229-231), own shard
