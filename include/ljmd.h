@@ -141,6 +141,15 @@ int ljmd_verlet_step(int32_t n, double box_length, double dt, double rc,
                      double *vx, double *vy, double *vz,
                      double *ax, double *ay, double *az,
                      double *epot, double *ekin, double *d_epot, double *dd_epot);
+/*
+ * Trajectory analysis pair pass: adds the ordered-pair distance histogram of ONE
+ * snapshot to hist[nbins] -- the O(n^2) loop of compute_rdf (scripts/md_one_run_analysis.py:556-584:
+ * d -= L*rint(d/L), r = sqrt(.), bin = int(r / (rmax/nbins)) for r < rmax; every unordered pair
+ * counts 2, exactly as the reference's np.add.at(hist, bins, 2.0)).  Integer counts, bit-exact.
+ * Host arrays in; device 0.  nbins <= 8192.
+ */
+int ljmd_rdf_histogram(int32_t n, const double *x, const double *y, const double *z, double box_length,
+                       int32_t nbins, double rmax, uint64_t *hist);
 /* Frees the cached engines of the stateless entry points. */
 void ljmd_stateless_reset(void);
 

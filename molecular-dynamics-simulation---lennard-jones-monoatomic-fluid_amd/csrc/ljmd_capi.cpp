@@ -1199,6 +1199,53 @@ int ljmd_verlet_step(int32_t n, double box_length, double dt, double rc, double 
     return rc_;
 }
 
+// ---- trajectory analysis: RDF pair pass -------------------------------------------------
+
+int ljmd_rdf_histogram(int32_t n, const double *x, const double *y, const double *z, double box_length,
+                       int32_t nbins, double rmax, uint64_t *hist)
+{
+    if (n < 2 || !x || !y || !z || !hist || nbins < 1 || nbins > 8192 || !(box_length > 0.0) || !(rmax > 0.0))
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_rdf_histogram: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LJMD_ERR_NO_DEVICE, "ljmd_rdf_histogram: no HIP device available (this library has no CPU path)");
+    LJMD_HIP(nullptr, hipSetDevice(0));
+    double *d = nullptr;
+    unsigned long long *dh = nullptr;
+    const size_t nb = (size_t)n * sizeof(double);
+    auto body = [&]() -> int {
+        LJMD_HIP(nullptr, hipMalloc(&d, 3 * nb));
+        LJMD_HIP(nullptr, hipMalloc(&dh, (size_t)nbins * sizeof(unsigned long long)));
+        LJMD_HIP(nullptr, hipMemcpy(d, x, nb, hipMemcpyHostToDevice));
+        LJMD_HIP(nullptr, hipMemcpy(d + n, y, nb, hipMemcpyHostToDevice));
+        LJMD_HIP(nullptr, hipMemcpy(d + 2 * (size_t)n, z, nb, hipMemcpyHostToDevice));
+        LJMD_HIP(nullptr, hipMemset(dh, 0, (size_t)nbins * sizeof(unsigned long long)));
+        RdfArgs a;
+        a.x = d;
+        a.y = d + n;
+        a.z = d + 2 * (size_t)n;
+        a.hist = dh;
+        a.n = n;
+        a.nbins = nbins;
+        a.L = box_length;
+        a.rmax = rmax;
+        a.dr = rmax / nbins;                         // as the reference: dr = rmax / nbins
+        const int row_blocks = (n + kBlock - 1) / kBlock;
+        int ns = std::max(1, std::min((kTargetWorkgroups + row_blocks - 1) / row_blocks, (n + 63) / 64));
+        a.chunk = (n + ns - 1) / ns;
+        ns = (n + a.chunk - 1) / a.chunk;
+        LJMD_HIP(nullptr, launch_rdf_histogram(a, dim3(row_blocks, ns), nullptr));
+        std::vector<unsigned long long> hh(nbins);
+        LJMD_HIP(nullptr, hipMemcpy(hh.data(), dh, (size_t)nbins * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int b = 0; b < nbins; ++b) hist[b] += hh[b];
+        return LJMD_OK;
+    };
+    const int rc_ = body();
+    (void)hipFree(d);
+    (void)hipFree(dh);
+    return rc_;
+}
+
 void ljmd_stateless_reset(void)
 {
     std::lock_guard<std::mutex> lock(g_cache_mutex);

@@ -103,6 +103,13 @@ struct GeometryArgs {
     double rsplit2;         // r_split^2
 };
 
+struct RdfArgs {
+    const double *x, *y, *z;       // [n] one snapshot, wrapped coordinates
+    unsigned long long *hist;      // [nbins] ordered-pair counts (added to)
+    int n, nbins, chunk;           // chunk = j per grid.y slice
+    double L, rmax, dr;
+};
+
 struct SortArgs {
     const double *r;        // own block [3][P]
     unsigned *keys;         // [P]
@@ -120,6 +127,7 @@ hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_
 hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, hipStream_t s);
+hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s);
 

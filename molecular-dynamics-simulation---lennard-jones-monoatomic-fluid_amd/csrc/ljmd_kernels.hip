@@ -921,6 +921,42 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinalizeArgs a)
     }
 }
 
+// ===========================================================================
+// Trajectory analysis pair pass: radial distribution histogram of ONE snapshot,
+// the O(n^2) loop of the reference's compute_rdf (scripts/md_one_run_analysis.py:556-584).
+// Bit-exact integer result: per pair the reference's numpy arithmetic with its roundings --
+//   d = x_j - x_i ; d -= L * rint(d / L)      (np.rint = half-to-even; a true division)
+//   r = sqrt(dx*dx + dy*dy + dz*dz)           (unfused, correctly rounded sqrt)
+//   if r < rmax: hist[int(r / dr)] += 2       (i<j pairs, weight 2)
+// evaluated here for every ORDERED pair with weight 1 (the arithmetic is symmetric in i, j).
+// One thread per i, j broadcast through scalar loads, histogram in LDS (ds_add_u32), one
+// 64-bit global atomic per bin and block; integer sums are order independent.
+// ===========================================================================
+__global__ __launch_bounds__(kBlock) void rdf_histogram_kernel(RdfArgs a)
+{
+    extern __shared__ unsigned lhist[];
+    for (int b = threadIdx.x; b < a.nbins; b += kBlock) lhist[b] = 0u;
+    __syncthreads();
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < a.n;
+    const double xi = live ? a.x[i] : 0.0, yi = live ? a.y[i] : 0.0, zi = live ? a.z[i] : 0.0;
+    const int j0 = blockIdx.y * a.chunk, j1 = min(j0 + a.chunk, a.n);
+    for (int j = j0; j < j1; ++j) {
+        double dx = a.x[j] - xi, dy = a.y[j] - yi, dz = a.z[j] - zi;
+        dx = dx - a.L * __builtin_rint(dx / a.L);
+        dy = dy - a.L * __builtin_rint(dy / a.L);
+        dz = dz - a.L * __builtin_rint(dz / a.L);
+        const double r = __builtin_sqrt(dx * dx + dy * dy + dz * dz);
+        if (live && j != i && r < a.rmax) {
+            const int bin = (int)(r / a.dr);
+            if (bin < a.nbins) atomicAdd(&lhist[bin], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < a.nbins; b += kBlock)
+        if (lhist[b]) atomicAdd(&a.hist[b], (unsigned long long)lhist[b]);
+}
+
 // ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
@@ -995,6 +1031,12 @@ hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s)
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(kinetic_fused_kernel, dim3((a.rows + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(rdf_histogram_kernel, grid, dim3(kBlock), (size_t)a.nbins * sizeof(unsigned), s, a);
     return hipGetLastError();
 }
 

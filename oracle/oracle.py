@@ -193,3 +193,22 @@ def ref_bench(n: int, ncalls: int):
     out = subprocess.run([str(REF_HARNESS), "bench", str(n), str(ncalls)], check=True, capture_output=True,
                          text=True).stdout.split()
     return float(out[2]), float(out[3])
+
+
+# ---- trajectory analysis pair pass (scripts/md_one_run_analysis.py:556-584) --------------------
+
+def rdf_histogram_np(x, y, z, L, nbins, rmax, hist) -> None:
+    """Adds ONE snapshot's pair-distance counts to hist (uint64[nbins]); every unordered pair counts 2,
+    same arithmetic, operation for operation, as the reference's inner loop (numpy, no FMA)."""
+    dr = rmax / nbins
+    n = len(x)
+    for i in range(n - 1):
+        dx = x[i + 1:] - x[i]
+        dy = y[i + 1:] - y[i]
+        dz = z[i + 1:] - z[i]
+        dx -= L * np.rint(dx / L)
+        dy -= L * np.rint(dy / L)
+        dz -= L * np.rint(dz / L)
+        r = np.sqrt(dx * dx + dy * dy + dz * dz)
+        bins = (r[r < rmax] / dr).astype(int)
+        np.add.at(hist, bins, np.uint64(2))
