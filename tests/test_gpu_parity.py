@@ -126,6 +126,30 @@ def test_short_cutoff_most_tile_pairs_skipped(oracle, n, rc_over_L, n3, monkeypa
     assert np.max(np.abs(sc - sc_o) / np.abs(sc_o)) < 1e-10
 
 
+@pytest.mark.parametrize("n", [1, 2, 4, 10, 65, 257])
+def test_tiny_systems_vs_oracle(oracle, n):
+    """Edge sizes: one particle (no pair, tail terms only), fewer particles than a tile, one more than a
+    tile / a workgroup (padding slots in the middle of the machinery)."""
+    p, r, v = synthetic.make_config(max(n, 2), seed=100 + n, rho=0.5, dt=0.002)   # jittered lattice sites, no overlaps
+    if n == 1:                                     # a single particle: no pairs at all, only the tail constants
+        p = init_params(1, p.box_length, p.dt, p.rc)
+        r, v = np.ascontiguousarray(r[:, :1]), np.zeros((3, 1))
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    st = {"rx": r[0].copy(), "ry": r[1].copy(), "rz": r[2].copy(), "ux": r[0].copy(), "uy": r[1].copy(),
+          "uz": r[2].copy(), "vx": v[0].copy(), "vy": v[1].copy(), "vz": v[2].copy(), "ax": ax.copy(), "ay": ay.copy(), "az": az.copy()}
+    sc_o = oracle.run_steps(po, 5, st)
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e, d, dd = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+        sc = np.stack(eng.verlet_steps(5), axis=1)
+    scale = max(np.abs(ax).max(), 1.0)
+    assert abs(e - e_o) <= 1e-12 * max(abs(e_o), 1.0) and abs(d - d_o) <= 1e-12 * max(abs(d_o), 1.0)
+    assert np.abs(a - np.stack([ax, ay, az])).max() <= 1e-12 * scale
+    assert np.max(np.abs(sc - sc_o) / np.maximum(np.abs(sc_o), 1.0)) < 1e-9
+
+
 def test_force_fcc108_known_answer(golden, oracle):
     g = golden("force_fcc108")
     L = float(g["L"])
