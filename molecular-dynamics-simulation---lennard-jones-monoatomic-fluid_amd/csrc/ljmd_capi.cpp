@@ -352,12 +352,13 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         LJMD_HIP(h, launch_tile_mask(ga, h->stream));
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
-            const dim3 grid((h->NGo + kWavesPerBlock - 1) / kWavesPerBlock, h->nslab_n);
+            const dim3 grid(h->NGo, h->nslab_n);                                       // one wave per workgroup
             LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->n3_waves, h->stream));   // all pairs, or the NEAR ones
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y;
             n3 = true;
             if (h->mode == LJMD_PRECISION_FP32_FORCE) {
+                const dim3 fgrid = grid;
                 // far pass in fp32: its own row-side slices, column-side slab and workgroup partials
                 N3Args fa = n3_args(h);
                 fa.mask = h->d_mask_far;
@@ -365,9 +366,9 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
                 fa.slab_j = h->d_slab_j2;
                 fa.flag_j = h->d_flag_j2;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
-                LJMD_HIP(h, launch_pair_n3_f32(fa, grid, h->stream));
+                LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, h->stream));
                 nslab *= 2;
-                n_wg *= 2;
+                n_wg += fgrid.x * fgrid.y;
             }
         } else {
             const dim3 grid(h->TB / kWavesPerBlock, h->nslab_t);
@@ -634,7 +635,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         const int n3_min = env_int("LJMD_N3_MIN_N", 16384);
         h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min;
         h->n3_waves = env_int("LJMD_N3_WAVES", 3);
-        const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 32768));
+        const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 65536));
         int ns = (target_waves + h->NGo - 1) / h->NGo;
         ns = std::max(1, std::min(ns, h->Dmax + 1));
         h->dchunk = (h->Dmax + 1 + ns - 1) / ns;
@@ -653,7 +654,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     }
     const int nslab_max = std::max(std::max(h->nslab_g, h->nslab_t), h->use_n3 ? h->nslab_n * (mixed ? 2 : 1) : 1);
     const int n_wg_max = std::max(row_blocks * std::max(h->nslab_g, h->nslab_t),
-                                  ((h->NGo + kWavesPerBlock - 1) / kWavesPerBlock) * h->nslab_n * (mixed ? 2 : 1));
+                                  h->NGo * h->nslab_n * (mixed ? 2 : 1));
     h->n_ke = row_blocks;
     h->h_perm.resize(h->P);
     for (int i = 0; i < h->P; ++i) h->h_perm[i] = i;

@@ -331,12 +331,12 @@ __device__ __forceinline__ bool uniform_image(double lo, double hi, double L, do
 }
 
 template <int MIN_WAVES>
-__global__ __launch_bounds__(kBlock, MIN_WAVES) void pair_n3_kernel(N3Args a)
+__global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
 {
-    __shared__ double red[2 * kWavesPerBlock];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int Al = blockIdx.x * kWavesPerBlock + wave;         // owned row group, wave-uniform
+    // ONE wave per workgroup: the waves are independent, and a 4-wave workgroup would hold its CU slots
+    // until its slowest wave (different mask density per row group) has finished
+    const int lane = threadIdx.x;
+    const int Al = blockIdx.x;                                 // owned row group, wave-uniform
     const bool active = Al < a.NGo;
     const int A = a.rank * a.NGo + Al;                         // its global index
     const size_t P = a.P;
@@ -482,12 +482,11 @@ __global__ __launch_bounds__(kBlock, MIN_WAVES) void pair_n3_kernel(N3Args a)
             si[2 * P + slot] = az[k];
         }
     }
-    double v[2] = {s12, s6};
-    block_sum<2>(v, red);
-    if (threadIdx.x == 0) {
+    const double t12 = wave_sum(s12), t6 = wave_sum(s6);
+    if (lane == 0) {
         double *w = a.wg_part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-        w[0] = v[0];
-        w[1] = v[1];
+        w[0] = t12;
+        w[1] = t6;
     }
 }
 
@@ -556,12 +555,10 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
     }
 }
 
-__global__ __launch_bounds__(kBlock, 4) void pair_n3_f32_kernel(N3Args a)
+__global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
 {
-    __shared__ double red[2 * kWavesPerBlock];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int Al = blockIdx.x * kWavesPerBlock + wave;
+    const int lane = threadIdx.x;                              // one wave per workgroup (see pair_n3_kernel)
+    const int Al = blockIdx.x;
     const bool active = Al < a.NGo;
     const int A = a.rank * a.NGo + Al;
     const size_t P = a.P;
@@ -672,12 +669,11 @@ __global__ __launch_bounds__(kBlock, 4) void pair_n3_f32_kernel(N3Args a)
             si[2 * P + slot] = az[k];
         }
     }
-    double v[2] = {s12, s6};
-    block_sum<2>(v, red);
-    if (threadIdx.x == 0) {
+    const double r12 = wave_sum(s12), r6 = wave_sum(s6);
+    if (lane == 0) {
         double *w = a.wg_part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-        w[0] = v[0];
-        w[1] = v[1];
+        w[0] = r12;
+        w[1] = r6;
     }
 }
 
@@ -976,17 +972,17 @@ hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t
 {
     // register budget variants (occupancy vs spills); the default is chosen by measurement
     if (min_waves <= 3)
-        hipLaunchKernelGGL(pair_n3_kernel<3>, grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(pair_n3_kernel<3>, grid, dim3(kTile), 0, s, a);
     else if (min_waves == 4)
-        hipLaunchKernelGGL(pair_n3_kernel<4>, grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(pair_n3_kernel<4>, grid, dim3(kTile), 0, s, a);
     else
-        hipLaunchKernelGGL(pair_n3_kernel<5>, grid, dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(pair_n3_kernel<5>, grid, dim3(kTile), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(pair_n3_f32_kernel, grid, dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL(pair_n3_f32_kernel, grid, dim3(kTile), 0, s, a);
     return hipGetLastError();
 }
 
