@@ -199,6 +199,7 @@ N3Args n3_args(ljmd_t *h)
     a.slab_j = h->d_slab_j;
     a.flag_j = h->d_flag_j;
     a.wg_part = h->d_wg_part;
+    a.S = h->S;
     a.P = h->P;
     a.G = h->G;
     a.rank = h->rank;

@@ -51,7 +51,7 @@ struct N3Args {
     double *slab_j;         // [NGo][Q][3][64] column-side partial accelerations, Q = (Dmax+1)*4
     unsigned char *flag_j;  // [NGo][Q] 1 = slab_j block written this step
     double *wg_part;        // [n workgroups][2]
-    int P, G, rank, TB, T, W;
+    int S, P, G, rank, TB, T, W;   // S = real particles per rank (slots S..P-1 are padding)
     int NG, NGo, Dmax, Q;   // row groups in total / owned by this rank (NGo = TB / 4, NG = G * NGo)
     int dchunk;             // offsets d per grid.y slice
     double L, invL, rc2;

@@ -269,6 +269,12 @@ __global__ __launch_bounds__(kBlock) void pair_tiles_kernel(PairArgs a)
 // mask are skipped (all four row tiles out => the column tile is not even loaded).
 // grid = (ceil(NG / 4), offset chunks); the waves of a workgroup are independent.
 // ===========================================================================
+
+// UNIFORM: the host-side geometry proved that every pair of this (row group, column tile) takes the
+// SAME periodic image on each axis, n = (sx, sy, sz) / L with |n| <= 2.  Then
+//   d = (xi - xj) - s      (two roundings: the difference, then the exact-product subtraction)
+// is bit-identical to fma(-L, rndne((xi - xj) * invL), xi - xj) and costs 2 instead of 4
+// instructions per axis.
 __device__ __forceinline__ double dpp_rotate(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -277,12 +283,7 @@ __device__ __forceinline__ double dpp_rotate(double v)
     return __hiloint2double(hi, lo);
 }
 
-// UNIFORM: the host-side geometry proved that every pair of this (row group, column tile) takes the
-// SAME periodic image on each axis, n = (sx, sy, sz) / L with |n| <= 2.  Then
-//   d = (xi - xj) - s      (two roundings: the difference, then the exact-product subtraction)
-// is bit-identical to fma(-L, rndne((xi - xj) * invL), xi - xj) and costs 2 instead of 4
-// instructions per axis.
-template <bool LANE_PRED, bool UNIFORM>
+template <bool LANE_PRED, int NU, bool INNER = false>
 __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
                                         double xj, double yj, double zj,
                                         double L, double invL, double rc2, bool lane_ok,
@@ -291,18 +292,14 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
                                         double &jx, double &jy, double &jz,
                                         double &s12, double &s6)
 {
-    double dx, dy, dz;
-    if constexpr (UNIFORM) {
-        dx = (xi - xj) - sx;
-        dy = (yi - yj) - sy;
-        dz = (zi - zj) - sz;
-    } else {
-        dx = mic_fast(xi - xj, L, invL);
-        dy = mic_fast(yi - yj, L, invL);
-        dz = mic_fast(zi - zj, L, invL);
-    }
+    // NU: bit k set = axis k needs the general minimum image (4 instructions); clear = the image is the
+    // same for the whole (row group, column tile) and the shift is subtracted (2 instructions)
+    const double dx = (NU & 1) ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
+    const double dy = (NU & 2) ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
+    const double dz = (NU & 4) ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
     const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
-    bool in = r2 < rc2;
+    bool in = true;
+    if constexpr (!INNER) in = r2 < rc2;       // INNER: the boxes prove r^2 < rc^2 for every pair
     if constexpr (LANE_PRED) in = in && lane_ok;
     if (in) {
         const double u = rcp_newton(r2);
@@ -317,6 +314,26 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
         jx = fma(-g, dx, jx);
         jy = fma(-g, dy, jy);
         jz = fma(-g, dz, jz);
+    }
+}
+
+// 64 rotation steps of one column tile against the wave's 4 row tiles (see pair_n3_kernel).
+template <int NU, bool MASKED, bool INNER>
+__device__ __forceinline__ void column_tile_loop(const double (&xi)[kRowTiles], const double (&yi)[kRowTiles],
+                                                 const double (&zi)[kRowTiles], double (&ax)[kRowTiles],
+                                                 double (&ay)[kRowTiles], double (&az)[kRowTiles],
+                                                 double xj, double yj, double zj, unsigned mb,
+                                                 double L, double invL, double rc2, double sx, double sy, double sz,
+                                                 double &jx, double &jy, double &jz, double &s12, double &s6)
+{
+    for (int s = 0; s < kTile; ++s) {
+#pragma unroll
+        for (int k = 0; k < kRowTiles; ++k)
+            if (!MASKED || ((mb >> k) & 1u))
+                pair_n3<false, NU, INNER>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
+                                          ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+        xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
+        jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
     }
 }
 
@@ -368,6 +385,7 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
         }
     }
 
+    const bool group_full = (kRowTiles * Al + kRowTiles) * kTile <= a.S;   // no padding slot among the 256 rows
     const int d0 = blockIdx.y * a.dchunk;
     const int d1 = active ? min(d0 + a.dchunk, a.Dmax + 1) : d0;
     for (int d = d0; d < d1; ++d) {
@@ -395,15 +413,29 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
             double xj = cb[0], yj = cb[P], zj = cb[2 * P];
             double jx = 0.0, jy = 0.0, jz = 0.0;
 
-            // same periodic image for every pair of (row group, column tile)?  (column box from bbox[])
+            // per axis: same periodic image for every pair of (row group, column tile)?  If so for all three,
+            // also: is every pair provably INSIDE the cutoff (no test needed)?  Column box from bbox[].
             double sx = 0.0, sy = 0.0, sz = 0.0;
-            bool uni;
+            int nu;
+            bool inner;
             {
                 const double *cbx = a.bbox + (size_t)c * kBoxStride;
-                const bool ux = uniform_image(glo[0] - cbx[3], ghi[0] - cbx[0], a.L, a.invL, sx);
-                const bool uy = uniform_image(glo[1] - cbx[4], ghi[1] - cbx[1], a.L, a.invL, sy);
-                const bool uz = uniform_image(glo[2] - cbx[5], ghi[2] - cbx[2], a.L, a.invL, sz);
-                uni = __builtin_amdgcn_readfirstlane((int)(ux && uy && uz)) != 0;
+                const double lo[3] = {glo[0] - cbx[3], glo[1] - cbx[4], glo[2] - cbx[5]};
+                const double hi[3] = {ghi[0] - cbx[0], ghi[1] - cbx[1], ghi[2] - cbx[2]};
+                const bool ux = uniform_image(lo[0], hi[0], a.L, a.invL, sx);
+                const bool uy = uniform_image(lo[1], hi[1], a.L, a.invL, sy);
+                const bool uz = uniform_image(lo[2], hi[2], a.L, a.invL, sz);
+                nu = __builtin_amdgcn_readfirstlane((ux ? 0 : 1) | (uy ? 0 : 2) | (uz ? 0 : 4));
+                const double fx = fmax(fabs(lo[0] - sx), fabs(hi[0] - sx)), fy = fmax(fabs(lo[1] - sy), fabs(hi[1] - sy)),
+                             fz = fmax(fabs(lo[2] - sz), fabs(hi[2] - sz));
+                // padding slots (NaN) must keep failing the cutoff test: INNER only for completely filled tiles
+                const bool full = group_full && ((c - (a.G == 1 ? 0 : c / a.TB) * a.TB) + 1) * kTile <= a.S;
+                inner = __builtin_amdgcn_readfirstlane(
+                            (int)(nu == 0 && full && (fx * fx + fy * fy + fz * fz) < a.rc2 * (1.0 - 1e-10))) != 0;
+                if (nu & 1) sx = 0.0;
+                if (nu & 2) sy = 0.0;
+                if (nu & 4) sz = 0.0;
+                if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
             }
 
             if (d == 0 && ((mb >> l) & 1u)) {
@@ -414,55 +446,29 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                         if (!((mb >> k) & 1u)) continue;
                         if (k == l) {
                             if (s >= 1 && s <= 32)
-                                pair_n3<true, false>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2,
-                                                     s < 32 || lane < 32, 0.0, 0.0, 0.0, ax[k], ay[k], az[k], jx,
-                                                     jy, jz, s12, s6);
+                                pair_n3<true, 7>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2,
+                                                 s < 32 || lane < 32, 0.0, 0.0, 0.0, ax[k], ay[k], az[k], jx,
+                                                 jy, jz, s12, s6);
                         } else {
-                            pair_n3<false, false>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0,
-                                                  0.0, 0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+                            pair_n3<false, 7>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0,
+                                              0.0, 0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
                         }
                     }
                     xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
                     jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
                 }
-            } else if (mb == 15u && uni) {
-                for (int s = 0; s < kTile; ++s) {
-#pragma unroll
-                    for (int k = 0; k < kRowTiles; ++k)
-                        pair_n3<false, true>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, sx, sy, sz,
-                                             ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
-                    xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
-                    jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
-                }
-            } else if (mb == 15u) {
-                for (int s = 0; s < kTile; ++s) {
-#pragma unroll
-                    for (int k = 0; k < kRowTiles; ++k)
-                        pair_n3<false, false>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0, 0.0,
-                                              0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
-                    xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
-                    jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
-                }
-            } else if (uni) {
-                for (int s = 0; s < kTile; ++s) {
-#pragma unroll
-                    for (int k = 0; k < kRowTiles; ++k)
-                        if ((mb >> k) & 1u)
-                            pair_n3<false, true>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, sx, sy,
-                                                 sz, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
-                    xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
-                    jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
-                }
             } else {
-                for (int s = 0; s < kTile; ++s) {
-#pragma unroll
-                    for (int k = 0; k < kRowTiles; ++k)
-                        if ((mb >> k) & 1u)
-                            pair_n3<false, false>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0,
-                                                  0.0, 0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
-                    xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
-                    jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
-                }
+#define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
+    column_tile_loop<NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, mb, a.L, a.invL, a.rc2, sx, sy, \
+                                           sz, jx, jy, jz, s12, s6)
+                const bool all4 = mb == 15u;
+                if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
+                else if (nu == 0)     { if (all4) LJMD_LOOP(0, false, false); else LJMD_LOOP(0, true, false); }
+                else if (nu == 1)     { if (all4) LJMD_LOOP(1, false, false); else LJMD_LOOP(1, true, false); }
+                else if (nu == 2)     { if (all4) LJMD_LOOP(2, false, false); else LJMD_LOOP(2, true, false); }
+                else if (nu == 4)     { if (all4) LJMD_LOOP(4, false, false); else LJMD_LOOP(4, true, false); }
+                else                  { if (all4) LJMD_LOOP(7, false, false); else LJMD_LOOP(7, true, false); }
+#undef LJMD_LOOP
             }
             double *o = a.slab_j + blk * (3 * kTile) + lane;
             o[0] = jx;
