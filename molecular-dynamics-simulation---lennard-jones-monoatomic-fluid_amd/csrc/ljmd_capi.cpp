@@ -67,6 +67,7 @@ struct ljmd {
     double *d_ru = nullptr, *d_v = nullptr, *d_a = nullptr;   // [3][P]
     double *d_slab = nullptr;     // [nslab_max][3][P]
     double *d_wg_part = nullptr;  // [n_wg_max][2]
+    double *d_fold = nullptr;     // [kFoldBlocks][2]
     double *d_ke_part = nullptr;  // [n_ke][3]
     double *d_ring = nullptr;     // [kRingCap][kPartialStride]
     unsigned *d_ring_pos = nullptr;
@@ -406,7 +407,7 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
         if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclReduceScatter failed: %s", ncclGetErrorString(r));
     }
     LJMD_HIP(h, launch_kick(integrate_args(h), kick, h->stream));
-    LJMD_HIP(h, launch_finalize(finalize_args(h, h->pending_n_wg, kick, h->pending_scale), h->stream));
+    LJMD_HIP(h, launch_finalize(finalize_args(h, h->pending_n_wg, kick, h->pending_scale), h->d_fold, h->stream));
     if (q) LJMD_HIP(h, hipEventRecord(q->e[4], h->stream));
     h->ring_issued++;
     h->have_accel = true;
@@ -482,7 +483,7 @@ void release(ljmd_t *h)
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv,
-                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2};
+                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -685,6 +686,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_fpart, P3 * (needs_force_exchange(h) ? h->G : 1)));
         if (needs_force_exchange(h)) LJMD_HIP(h, hipMalloc(&h->d_frecv, P3));
         LJMD_HIP(h, hipMalloc(&h->d_ke_part, 3 * (size_t)h->n_ke * sizeof(double)));
+        LJMD_HIP(h, hipMalloc(&h->d_fold, 2 * (size_t)kFoldBlocks * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring, (size_t)kRingCap * kPartialStride * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring_pos, sizeof(unsigned)));
         LJMD_HIP(h, hipMalloc(&h->d_bbox, (size_t)h->T * kBoxStride * sizeof(double)));

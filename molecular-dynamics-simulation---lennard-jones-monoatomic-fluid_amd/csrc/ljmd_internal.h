@@ -20,6 +20,7 @@ constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kTile = 64;                   // particles per tile = one wave
 constexpr int kRowTiles = 4;                // tiles per Newton-3 row group (particles per lane)
 constexpr int kPartialStride = 8;           // doubles per per-rank per-step partial record
+constexpr int kFoldBlocks = 128;             // pre-reduction blocks of the scalar partials (large grids)
 constexpr int kBoxStride = 8;               // doubles per tile bounding box (lo xyz, hi xyz, 2 pad)
 
 struct PairArgs {
@@ -126,7 +127,7 @@ hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);
 hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);
-hipError_t launch_finalize(const FinalizeArgs &a, hipStream_t s);
+hipError_t launch_finalize(const FinalizeArgs &a, double *fold_scratch /* [2 * kFoldBlocks] or NULL */, hipStream_t s);
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s);

@@ -888,6 +888,27 @@ __global__ __launch_bounds__(kBlock) void kinetic_fused_kernel(IntegrateArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// K4 pre-stage for large grids: block b folds the contiguous slice b of the per-workgroup pair sums
+// into one pair (fixed order), so that the single-block finalize below reads at most kFoldBlocks pairs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fold_partials_kernel(const double *wg_part, double *folded, int n_wg)
+{
+    __shared__ double red[2 * kWavesPerBlock];
+    const int per = (n_wg + gridDim.x - 1) / gridDim.x;
+    const int w0 = blockIdx.x * per, w1 = min(w0 + per, n_wg);
+    double v[2] = {0.0, 0.0};
+    for (int w = w0 + threadIdx.x; w < w1; w += kBlock) {
+        v[0] += wg_part[2 * (size_t)w];
+        v[1] += wg_part[2 * (size_t)w + 1];
+    }
+    block_sum<2>(v, red);
+    if (threadIdx.x == 0) {
+        folded[2 * blockIdx.x] = v[0];
+        folded[2 * blockIdx.x + 1] = v[1];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K4: one block folds the per-workgroup partials into ONE partial record of this
 // rank for this step, appended to the scalar ring at *ring_pos:
 //   rec = { S12, S6, Kx, Ky, Kz, 0, 0, 0 }    (kPartialStride doubles)
@@ -1042,8 +1063,14 @@ hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(const FinalizeArgs &a, hipStream_t s)
+hipError_t launch_finalize(const FinalizeArgs &a_in, double *fold_scratch, hipStream_t s)
 {
+    FinalizeArgs a = a_in;
+    if (a.n_wg > 4096 && fold_scratch) {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(kFoldBlocks), dim3(kBlock), 0, s, a.wg_part, fold_scratch, a.n_wg);
+        a.wg_part = fold_scratch;
+        a.n_wg = kFoldBlocks;
+    }
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
