@@ -791,23 +791,27 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
 template <bool N3>
 __global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
 {
-    const int i = blockIdx.x * kBlock + threadIdx.x;            // slot inside the block
+    // 64 slots (one tile) per workgroup; the 4 waves split the terms of every slot's sum 4 ways
+    // (wave q takes slices / row groups q, q+4, ...) and the four partial sums are combined through LDS
+    // in fixed order: 4x the loads in flight of a one-thread-per-slot loop, still bitwise reproducible.
+    __shared__ double part[kWavesPerBlock][3][kTile];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * kTile + lane;                    // slot inside the block
     const int g = (gridDim.y == 1) ? a.rank : (int)blockIdx.y;  // whose particles
     double s[3] = {0.0, 0.0, 0.0};
     if (g == a.rank) {
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            const size_t o = (size_t)ax * a.P + i;
-            s[ax] = a.slab[o];
-            for (int c = 1; c < a.nslab; ++c) s[ax] += a.slab[(size_t)c * 3 * a.P + o];
+        for (int c = q; c < a.nslab; c += kWavesPerBlock) {
+            const double *sl = a.slab + (size_t)c * 3 * a.P + i;
+            s[0] += sl[0];
+            s[1] += sl[a.P];
+            s[2] += sl[2 * (size_t)a.P];
         }
     }
     if constexpr (N3) {
-        const int tl = i / kTile, lane = i - tl * kTile;
-        const int c = g * a.TB + tl;                            // global column tile
+        const int c = g * a.TB + blockIdx.x;                    // global column tile (= this workgroup's tile)
         const int B = c / kRowTiles, l = c - B * kRowTiles;
         const int A0 = a.rank * a.NGo;
-        for (int Al = 0; Al < a.NGo; ++Al) {
+        for (int Al = q; Al < a.NGo; Al += kWavesPerBlock) {
             int d = B - (A0 + Al);
             if (d < 0) d += a.NG;
             if (d > a.Dmax) continue;
@@ -826,10 +830,19 @@ __global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
             }
         }
     }
-    double *o = a.fpart + (size_t)(gridDim.y == 1 ? 0 : g) * 3 * a.P + i;
-    o[0] = s[0];
-    o[a.P] = s[1];
-    o[2 * (size_t)a.P] = s[2];
+    part[q][0][lane] = s[0];
+    part[q][1][lane] = s[1];
+    part[q][2][lane] = s[2];
+    __syncthreads();
+    if (q == 0) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double t = part[0][ax][lane];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) t += part[w][ax][lane];
+            a.fpart[(size_t)(gridDim.y == 1 ? 0 : g) * 3 * a.P + (size_t)ax * a.P + i] = t;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1033,7 +1046,7 @@ hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s)
 
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s)
 {
-    const dim3 grid(a.P / kBlock, all_blocks ? a.G : 1);
+    const dim3 grid(a.P / kTile, all_blocks ? a.G : 1);
     if (a.slab_j)
         hipLaunchKernelGGL(reduce_forces_kernel<true>, grid, dim3(kBlock), 0, s, a);
     else
