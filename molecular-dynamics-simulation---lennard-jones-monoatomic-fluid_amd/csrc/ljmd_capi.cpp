@@ -58,7 +58,7 @@ struct ljmd {
     bool have_state = false, have_accel = false;
     bool sort_enabled = true;
     bool force_generic = false;       // LJMD_FORCE_GENERIC=1: always take the exact generic kernel (A/B tests)
-    int resort_every = 10, steps_since_sort = 0, ncell = 1;
+    int resort_every = 20, steps_since_sort = 0, ncell = 1;
 
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;        // RCCL communicator over the G ranks (multi-GPU only)
@@ -590,7 +590,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     // below ~16 tiles there is nothing for the tile mask to skip: keep the caller's order
     h->sort_enabled = env_int("LJMD_SORT", 1) != 0 && n >= env_int("LJMD_SORT_MIN_N", 1024);
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
-    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", 10));
+    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", 20));
     h->ncell = std::max(1, std::min(1023, (int)std::floor(box_length / 1.2)));
     h->kd_sort = env_int("LJMD_SORT_KD", 1) != 0;
     std::vector<int> kd_offsets;

@@ -384,12 +384,12 @@ def test_resort_keeps_particle_identity(golden):
         assert np.array_equal(st["ru"][1], tag * 2)
         eng.set_unwrapped(r0[0], r0[1], r0[2])
         eng.compute_forces()
-        eng.verlet_steps(35)                      # crosses three re-sorts (every 10 steps)
+        eng.verlet_steps(65)                      # crosses three re-sorts (every 20 steps)
         fin = eng.get_state(("r", "ru"))
     # unwrapped - wrapped must be an integer number of box lengths for the SAME particle
     k = (np.stack(fin["ru"]) - np.stack(fin["r"])) / p.box_length
     assert np.max(np.abs(k - np.round(k))) < 1e-9
-    assert np.max(np.abs(np.stack(fin["ru"]) - r0)) < 1.0    # nobody moved a sigma in 35 steps
+    assert np.max(np.abs(np.stack(fin["ru"]) - r0)) < 1.5    # nobody moved far in 65 steps (t = 0.33)
 
 
 @pytest.mark.parametrize("split", ["5", "0"])
