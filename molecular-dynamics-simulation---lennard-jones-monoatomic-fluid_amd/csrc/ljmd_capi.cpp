@@ -91,7 +91,7 @@ struct ljmd {
     unsigned ring_issued = 0;     // host mirror: finalize launches issued
     // launch geometry
     int nslab_g = 1, chunk_g = 0;     // generic kernel: grid (P/256, nslab_g), chunk_g j per slice
-    int nslab_t = 1, chunk_t = 0;     // tile kernel:    grid (TB/4, nslab_t), chunk_t mask words per slice
+    int nslab_t = 1, chunk_t = 0;     // tile kernel:    grid (TB/4, nslab_t), chunk_t column tiles per slice
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
     int n3_waves = 3;                 // LJMD_N3_WAVES: register-budget variant of the Newton-3 kernel
@@ -623,11 +623,11 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->chunk_g = ((n + ns - 1) / ns + 7) / 8 * 8;
         h->nslab_g = (n + h->chunk_g - 1) / h->chunk_g;
     }
-    {   // tile kernel: slices over the W mask words
+    {   // tile (gather) kernel: slices of column tiles
         int ns = (kTargetWorkgroups + row_blocks - 1) / row_blocks;
-        ns = std::max(1, std::min(ns, h->W));
-        h->chunk_t = (h->W + ns - 1) / ns;
-        h->nslab_t = (h->W + h->chunk_t - 1) / h->chunk_t;
+        ns = std::max(1, std::min(ns, h->T));
+        h->chunk_t = (h->T + ns - 1) / ns;
+        h->nslab_t = (h->T + h->chunk_t - 1) / h->chunk_t;
     }
     {   // Newton-3 kernel: NG row groups over all ranks, NGo owned; offsets 0..Dmax in slices
         h->NGo = h->TB / kRowTiles;

@@ -36,7 +36,7 @@ struct PairArgs {
     int TB;                 // tiles per rank block
     int T;                  // tiles in total
     int W;                  // 64-bit mask words per row = ceil(T / 64)
-    int chunk;              // generic kernel: j slots per grid.y slice; tile kernel: mask words per slice
+    int chunk;              // generic kernel: j slots per grid.y slice; tile kernel: column tiles per slice
     double L, invL, rc2;
 };
 

@@ -184,7 +184,7 @@ __device__ __forceinline__ void pair_fast(double xi, double yi, double zi,
 // least one particle that can be within rc of tile I -- built by tile_mask_kernel from exact
 // bounding boxes) and for every set bit evaluates the 64 x 64 ordered pairs: the j
 // coordinates are wave-uniform, fetched with scalar loads and used as SGPR operands.
-// grid = (TB / 4, mask-word chunks).  Output as in the generic kernel.
+// grid = (TB / 4, column-tile slices).  Output as in the generic kernel.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void pair_tiles_kernel(PairArgs a)
 {
@@ -200,9 +200,12 @@ __global__ __launch_bounds__(kBlock) void pair_tiles_kernel(PairArgs a)
     double ax = 0.0, ay = 0.0, az = 0.0, s12 = 0.0, s6 = 0.0;
 
     const uint64_t *mrow = a.mask + (size_t)Il * a.W;
-    const int w0 = blockIdx.y * a.chunk, w1 = min(w0 + a.chunk, a.W);
-    for (int w = w0; w < w1; ++w) {
+    // this workgroup's slice of the column tiles: [J0, J1)  (a.chunk tiles; small systems get many slices)
+    const int J0 = blockIdx.y * a.chunk, J1 = min(J0 + a.chunk, a.T);
+    for (int w = J0 >> 6; w <= (J1 - 1) >> 6 && J0 < J1; ++w) {
         uint64_t m = mrow[w];
+        const int lo = max(J0 - w * 64, 0), hi = min(J1 - w * 64, 64);      // bits of this word inside the slice
+        m &= (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
         while (m) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
