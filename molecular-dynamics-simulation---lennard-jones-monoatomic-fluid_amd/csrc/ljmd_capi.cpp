@@ -291,7 +291,8 @@ EventSet *next_events(ljmd_t *h)
 int resort(ljmd_t *h, bool with_accel)
 {
     if (h->kd_sort) {
-        // recursive median split (ljmd_sort.hip): one segmented sort per level, axis = level % 3
+        // recursive median split (ljmd_sort.hip): one composite-key radix sort per level, along the axis
+        // chosen for that level at set_state (longest remaining extent of the shard)
         LJMD_HIP(h, launch_iota(h->d_idx, h->P, h->stream));
         LJMD_HIP(h, hipMemcpyAsync(h->d_idx2, h->d_idx, (size_t)h->P * sizeof(int), hipMemcpyDeviceToDevice,
                                    h->stream));   // slots S..P-1 (padding) keep their identity in both buffers
