@@ -92,7 +92,6 @@ def test_production_kernel_configuration_vs_oracle_n32768(oracle):
     po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
     e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
     with Engine(p) as eng:
-        assert eng.pair_kernel_name() == "pair_n3_kernel" or True      # name is final only after set_state
         eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         assert eng.pair_kernel_name() == "pair_n3_kernel"
         e, d, dd = eng.compute_forces()
