@@ -297,9 +297,10 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
 {
     // NU: bit k set = axis k needs the general minimum image (4 instructions); clear = the image is the
     // same for the whole (row group, column tile) and the shift is subtracted (2 instructions)
-    const double dx = (NU & 1) ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
-    const double dy = (NU & 2) ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
-    const double dz = (NU & 4) ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
+    // NU == 8: the common image is n = 0 on all three axes: d = xi - xj (1 instruction per axis)
+    const double dx = (NU == 8) ? (xi - xj) : (NU & 1) ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
+    const double dy = (NU == 8) ? (yi - yj) : (NU & 2) ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
+    const double dz = (NU == 8) ? (zi - zj) : (NU & 4) ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
     const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
     bool in = true;
     if constexpr (!INNER) in = r2 < rc2;       // INNER: the boxes prove r^2 < rc^2 for every pair
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 if (nu & 2) sy = 0.0;
                 if (nu & 4) sz = 0.0;
                 if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
+                if (nu == 0 && sx == 0.0 && sy == 0.0 && sz == 0.0) nu = 8;   // no periodic image at all
             }
 
             if (d == 0 && ((mb >> l) & 1u)) {
@@ -465,7 +467,9 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
     column_tile_loop<NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, mb, a.L, a.invL, a.rc2, sx, sy, \
                                            sz, jx, jy, jz, s12, s6)
                 const bool all4 = mb == 15u;
-                if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
+                if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
+                else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
+                else if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
                 else if (nu == 0)     { if (all4) LJMD_LOOP(0, false, false); else LJMD_LOOP(0, true, false); }
                 else if (nu == 1)     { if (all4) LJMD_LOOP(1, false, false); else LJMD_LOOP(1, true, false); }
                 else if (nu == 2)     { if (all4) LJMD_LOOP(2, false, false); else LJMD_LOOP(2, true, false); }
