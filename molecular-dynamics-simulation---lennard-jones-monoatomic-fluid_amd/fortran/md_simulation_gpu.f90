@@ -6,11 +6,12 @@
 !   in : inputs/input_simulation_parameters.txt, outputs/rv_init.dat
 !   out: outputs/one_run/instantaneous_energies.dat   header :294, rows :374
 !        outputs/one_run/rva.dat                      header :254-257, records :384-387
+!        outputs/one_run/corr_*.dat, corrmean_*.dat, md_final_results.txt   :401-560
+!        (module md_stats / md_run_outputs: same estimators, same formats)
 ! Differences: the state lives in HBM for the whole run (ljmd_verlet_steps advances up to the
 ! next sampling step without touching the host; r, ru, v, a come back only when a snapshot is
-! written), the per-step unwrapped-coordinate update (:339-353) happens inside the drift
-! kernel, and the statistics / correlation post-processing (:401-560) is not part of this
-! driver.  Environment: LJMD_DEVICE (default 0).
+! written) and the per-step unwrapped-coordinate update (:339-353) happens inside the drift
+! kernel.  Environment: LJMD_DEVICE (default 0).
 !==============================================================================
 program md_simulation_gpu
   use, intrinsic :: iso_c_binding
@@ -18,6 +19,8 @@ program md_simulation_gpu
   use md_types,         only: sim_params, sim_state, init_state
   use read_input_files, only: read_simulation_parameters
   use ljmd_c_api
+  use md_stats,         only: run_statistics, stats_begin, stats_push
+  use md_run_outputs,   only: write_run_statistics
   implicit none
 
   type(sim_params) :: params
@@ -26,11 +29,12 @@ program md_simulation_gpu
   real(kind=dp_kind), allocatable, target :: s_epot(:), s_ekin(:), s_depot(:), s_ddepot(:)
   integer(kind=int_kind) :: total_steps, output_interval, warmup_steps, n_snapshots_expected
   real(kind=dp_kind) :: rc_over_L, target_total_energy
-  real(kind=dp_kind) :: epot, ekin, etot, d_epot, dd_epot, time, temp_inst, press_inst, npd, rho
+  real(kind=dp_kind) :: epot, ekin, etot, d_epot, dd_epot, time, temp_inst, press_inst, npd
   integer(kind=int_kind) :: step, next_sample, count, k, num_samples
   integer :: iu_rva, iu_out, ios, device
   integer(kind=8) :: c0, c1, crate
   type(c_ptr) :: engine
+  type(run_statistics) :: stats
   character(len=32) :: env
 
   call read_simulation_parameters('inputs/input_simulation_parameters.txt', params, total_steps, &
@@ -70,7 +74,7 @@ program md_simulation_gpu
   allocate(s_epot(output_interval + warmup_steps + 1), s_ekin(output_interval + warmup_steps + 1), &
            s_depot(output_interval + warmup_steps + 1), s_ddepot(output_interval + warmup_steps + 1))
   npd = dble(params%n)
-  rho = npd / params%volume
+  call stats_begin(stats, params%n, params%volume, n_snapshots_expected)
   num_samples = 0
   step = 0
   call system_clock(c0, crate)
@@ -92,8 +96,7 @@ program md_simulation_gpu
     etot = epot + ekin
     if (step > warmup_steps .and. mod(step, output_interval) == 0) then
       num_samples = num_samples + 1
-      temp_inst = 2.d0 * ekin / (3.d0 * npd)                               ! md_means.f90:221
-      press_inst = rho * temp_inst + (-d_epot) / (3.d0 * params%volume)    ! md_means.f90:227, virial = -d_epot (:366)
+      call stats_push(stats, epot, ekin, d_epot, dd_epot, temp_inst, press_inst)   ! T, P as md_means.f90:221,227
       write(iu_out, '(1pe13.6,5(2x,1pe13.6))') time, epot, ekin, etot, temp_inst, press_inst
       call ljmd_check(ljmd_get_state(engine, c_loc(state%rx), c_loc(state%ry), c_loc(state%rz), &
                                      c_loc(rux), c_loc(ruy), c_loc(ruz), &
@@ -111,6 +114,7 @@ program md_simulation_gpu
   call ljmd_destroy(engine)
 
   if (num_samples <= 0) stop 'md_simulation: no samples were taken (check warmup_steps/output_interval).'
+  call write_run_statistics('outputs/one_run', params, total_steps, output_interval, warmup_steps, stats)
   write(*, '(a,i0,a,i0,a,f10.2,a,es11.4,a)') 'md_simulation_gpu: N=', params%n, ' steps=', total_steps, &
     '  ', dble(total_steps) * dble(crate) / dble(max(c1 - c0, 1_8)), ' steps/s  ', &
     0.5d0 * npd * (npd - 1.d0) * dble(total_steps) * dble(crate) / dble(max(c1 - c0, 1_8)), ' pair-interactions/s'

@@ -1,8 +1,8 @@
 """Production-run loop around the resident engine: the host-side mirror of
 `program md_simulation` (scripts/md_simulation_program.f90:208-391) restricted to what
 touches the hot path -- parameter + rv_init input, t=0 forces, the MD loop, the sampling
-condition, instantaneous_energies.dat and rva.dat output.  The statistics modules
-(md_means accumulators, md_correlations, thermodynamic_coefs) are out of scope.
+condition, instantaneous_energies.dat and rva.dat output -- plus the end-of-run statistics
+files (:401-560) through `stats`.
 
 Between two sampling steps the state never leaves HBM: the loop advances
 `steps until next sample` with one ljmd_verlet_steps call and reads r/ru/v/a back only
@@ -15,8 +15,8 @@ from pathlib import Path
 
 import numpy as np
 
-from . import io_formats
-from .physics import Engine, observables
+from . import io_formats, stats
+from .physics import Engine
 from .read_input_files import RunControl, read_simulation_parameters
 
 
@@ -30,11 +30,13 @@ class RunResult:
     temp: list = field(default_factory=list)
     press: list = field(default_factory=list)
     steps_per_second: float = 0.0
+    summary: dict = field(default_factory=dict)     # means, stds, thermodynamic coefficients
 
 
 def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunResult:
     """Runs `root_dir/inputs/input_simulation_parameters.txt` from `root_dir/outputs/rv_init.dat`
-    and writes root_dir/outputs/one_run/{instantaneous_energies.dat, rva.dat}."""
+    and writes root_dir/outputs/one_run/{instantaneous_energies.dat, rva.dat, corr_*.dat,
+    corrmean_*.dat, md_final_results.txt}."""
     import time as _time
 
     root = Path(root_dir)
@@ -48,6 +50,7 @@ def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunR
 
     n_snap = max(0, ctl.total_steps // ctl.output_interval - ctl.warmup_steps // ctl.output_interval)  # :254-255
     res = RunResult()
+    acc = stats.RunStatistics(p.n, p.volume)                     # md_means_init (:272)
     with Engine(p, device=device) as eng:
         eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])        # :221-231 (ru <- r)
         eng.compute_forces()                                     # :236
@@ -65,13 +68,14 @@ def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunR
                 nxt += ctl.output_interval
             nxt = min(nxt, ctl.total_steps)
             count = nxt - step
-            epot, ekin, d_epot, _dd = eng.verlet_steps(count)
+            epot, ekin, d_epot, dd_epot = eng.verlet_steps(count)
             for _ in range(count):
                 t = t + p.dt                                      # :356 accumulated, not step*dt
             step = nxt
             if step > ctl.warmup_steps and step % ctl.output_interval == 0:
-                e, k, d = epot[-1], ekin[-1], d_epot[-1]
-                etot, temp, press = observables(p, e, k, d)
+                e, k = float(epot[-1]), float(ekin[-1])
+                temp, press = acc.push(e, k, d_epot[-1], dd_epot[-1])                   # :371-372
+                etot = e + k
                 f_en.write(io_formats.energies_row(t, e, k, etot, temp, press) + "\n")   # :374
                 res.n_samples += 1
                 for lst, val in ((res.time, t), (res.epot, e), (res.ekin, k), (res.etot, etot),
@@ -85,5 +89,7 @@ def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunR
         if rva is not None:
             rva.close()
     if res.n_samples <= 0:
-        raise ValueError("md_simulation: no samples were taken (check warmup_steps/output_interval).")  # :396
+        raise ValueError("md_simulation: no samples were taken (check warmup_steps/output_interval).")  # :399
+    res.summary = stats.write_run_statistics(out_dir, p, ctl.total_steps, ctl.output_interval,
+                                             ctl.warmup_steps, acc)
     return res

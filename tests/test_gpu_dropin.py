@@ -43,6 +43,54 @@ def _compare_run(tmp_path, src, n_rows):
     assert head == "# time   epot   ekin   etot   T   P"
 
 
+def _compare_statistics_files(out_dir, src):
+    """corr_*.dat, corrmean_*.dat and md_final_results.txt of a GPU run against the reference's files.
+    The GPU trajectory stays within ~1e-7 of the reference up to step 1000 (DESIGN 3.3), so sample means
+    agree to 1e-6; fluctuation quantities (std, coefficients, autocovariances) amplify that by the
+    ratio value/fluctuation, hence the looser bounds.  (With IDENTICAL samples the files are
+    byte-identical: tests/test_stats.py.)"""
+    mine = (out_dir / "md_final_results.txt").read_text().split()
+    ref = (src / "md_final_results.txt").read_text().split()
+    assert len(mine) == len(ref)
+    pairs = [(a, b) for a, b in zip(mine, ref)]
+    assert all(a == b for a, b in pairs if not _isnum(b))                  # labels and layout
+    nums = [(float(a), float(b)) for a, b in pairs if _isnum(b)]
+    assert len(nums) == 32
+    for a, b in nums[:9]:                                                    # run parameters: exact
+        assert a == b
+    for k, (a, b) in enumerate(nums[9:19]):                                  # <.> (even k) 1e-6, std (odd k) 1e-3
+        assert abs(a - b) <= (1e-6 if k % 2 == 0 else 1e-3) * abs(b), (k, a, b)
+    for a, b in nums[19:]:                                                   # coefficients
+        assert abs(a - b) <= 1e-3 * abs(b), (a, b)
+    for kind in ("corr", "corrmean"):
+        for obs in ("epot", "ekin", "etot", "temp", "press"):
+            m = np.loadtxt(out_dir / f"{kind}_{obs}.dat")
+            r = np.loadtxt(src / f"{kind}_{obs}.dat")
+            assert m.shape == r.shape
+            assert (out_dir / f"{kind}_{obs}.dat").read_text().splitlines()[0] == \
+                   (src / f"{kind}_{obs}.dat").read_text().splitlines()[0]
+            assert np.array_equal(m[:, 0], r[:, 0])
+            assert np.abs(m[:, 1] - r[:, 1]).max() <= 1e-3 * abs(r[0, 1]), (kind, obs)
+            assert np.abs(m[:, 2] - r[:, 2]).max() <= 1e-3, (kind, obs)
+
+
+@pytest.mark.parametrize("tag,n_rows", [("oi10", 90), ("oi100", 9)])
+def test_thin_fortran_driver_statistics_files(tmp_path, tag, n_rows):
+    """SURVEY 8(f) #4: the thin driver also writes the end-of-run statistics files."""
+    src = _workdir(tmp_path, tag)
+    subprocess.run([str(PKG / "bin" / "md_simulation_gpu")], cwd=tmp_path, check=True, timeout=120)
+    _compare_run(tmp_path, src, n_rows)
+    _compare_statistics_files(tmp_path / "outputs" / "one_run", src)
+
+
+def test_python_production_loop_statistics_files(tmp_path):
+    from ljmd_amd import simulation
+    src = _workdir(tmp_path, "oi10")
+    res = simulation.run_md_simulation(tmp_path)
+    assert res.n_samples == 90 and "gamma" in res.summary["coefficients"]
+    _compare_statistics_files(tmp_path / "outputs" / "one_run", src)
+
+
 def test_thin_fortran_driver_config1(tmp_path):
     exe = PKG / "bin" / "md_simulation_gpu"
     assert exe.exists(), "run __graft_entry__.build() first"
