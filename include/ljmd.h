@@ -120,6 +120,33 @@ int ljmd_compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot
 int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps,
                       double *epot, double *ekin, double *d_epot, double *dd_epot);
 
+/*
+ * Asynchronous form of the production loop (md_simulation_program.f90:300-391), so that the
+ * host's snapshot I/O (:374-387) overlaps the GPU's next steps instead of stalling them:
+ *
+ *   ljmd_enqueue_steps(h, k)      k Verlet steps on the engine's stream; returns at once.
+ *                                 At most LJMD_MAX_PENDING_STEPS steps may be pending.
+ *   ljmd_collect_steps(h, k, ..)  waits for the engine's stream and returns the scalars of the
+ *                                 last k enqueued steps (arrays of k doubles or NULL).
+ *   ljmd_snapshot_begin(h)        stream-ordered copy of r, ru, v, a (and the slot order) into
+ *                                 a device snapshot buffer -- a few microseconds behind the
+ *                                 steps enqueued so far -- then HBM -> pinned host on a SECOND
+ *                                 stream; returns at once.  Steps enqueued afterwards run
+ *                                 concurrently with that transfer and do not alter the snapshot.
+ *   ljmd_snapshot_end(h, ...)     waits for the transfer only (not for the engine's stream) and
+ *                                 delivers the twelve arrays as ljmd_get_state does.
+ * One snapshot may be in flight at a time (LJMD_ERR_STATE otherwise).
+ */
+#define LJMD_MAX_PENDING_STEPS 4096
+int ljmd_enqueue_steps(ljmd_t *h, int32_t nsteps);
+int ljmd_collect_steps(ljmd_t *h, int32_t nsteps,
+                       double *epot, double *ekin, double *d_epot, double *dd_epot);
+int ljmd_snapshot_begin(ljmd_t *h);
+int ljmd_snapshot_end(ljmd_t *h, double *rx, double *ry, double *rz,
+                      double *ux, double *uy, double *uz,
+                      double *vx, double *vy, double *vz,
+                      double *ax, double *ay, double *az);
+
 /* Kinetic energy of the resident velocities, one fused sum as at
  * md_simulation_program.f90:238-240 (t = 0 only). */
 int ljmd_kinetic_energy(ljmd_t *h, double *ekin);

@@ -54,6 +54,10 @@ PROTOTYPES = {
     "ljmd_get_state": (C.c_int, [C.c_void_p] + [c_double_p] * 12),
     "ljmd_compute_forces": (C.c_int, [C.c_void_p] + [c_double_p] * 3),
     "ljmd_verlet_steps": (C.c_int, [C.c_void_p, C.c_int32] + [c_double_p] * 4),
+    "ljmd_enqueue_steps": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ljmd_collect_steps": (C.c_int, [C.c_void_p, C.c_int32] + [c_double_p] * 4),
+    "ljmd_snapshot_begin": (C.c_int, [C.c_void_p]),
+    "ljmd_snapshot_end": (C.c_int, [C.c_void_p] + [c_double_p] * 12),
     "ljmd_kinetic_energy": (C.c_int, [C.c_void_p, c_double_p]),
     "ljmd_compute_lj_potential_energy": (C.c_int, [C.c_int32, C.c_double, C.c_double]
                                          + [c_double_p] * 9),

@@ -116,6 +116,14 @@ struct ljmd {
     std::vector<int> h_perm;      // slot -> original local index (>= S on padding)
     bool perm_dirty = false;
 
+    // asynchronous snapshot (ljmd_snapshot_begin/end): device copy of r, ru, v, a [4][3][P] + perm [P],
+    // its pinned host mirror, the second stream that carries the HBM -> host transfer
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_snap_ready = nullptr, ev_snap_done = nullptr;
+    double *d_snap = nullptr, *h_snap = nullptr;
+    int *d_snap_perm = nullptr, *h_snap_perm = nullptr;
+    bool snap_in_flight = false;
+
     bool profiling = false;
     std::vector<EventSet> ev_pool;
     size_t ev_used = 0;
@@ -488,6 +496,16 @@ void release(ljmd_t *h)
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
+    if (h->copy_stream) {
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamDestroy(h->copy_stream);
+    }
+    if (h->ev_snap_ready) (void)hipEventDestroy(h->ev_snap_ready);
+    if (h->ev_snap_done) (void)hipEventDestroy(h->ev_snap_done);
+    if (h->d_snap) (void)hipFree(h->d_snap);
+    if (h->d_snap_perm) (void)hipFree(h->d_snap_perm);
+    if (h->h_snap) (void)hipHostFree(h->h_snap);
+    if (h->h_snap_perm) (void)hipHostFree(h->h_snap_perm);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -563,7 +581,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     h->G = n_ranks;
     h->rank = rank;
     h->S = n / n_ranks;
-    h->P = ((h->S + kBlock - 1) / kBlock) * kBlock;
+    h->P = ((h->S + kSlotAlign - 1) / kSlotAlign) * kSlotAlign;
     h->TB = h->P / kTile;
     h->T = h->G * h->TB;
     h->W = (h->T + 63) / 64;
@@ -897,6 +915,104 @@ int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, dou
                         dd_epot ? dd_epot + done + s : nullptr);
         done += batch;
     }
+    return LJMD_OK;
+}
+
+// ---- asynchronous production loop ---------------------------------------------
+
+int ljmd_enqueue_steps(ljmd_t *h, int32_t nsteps)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_enqueue_steps: NULL handle");
+    if (nsteps < 0) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_enqueue_steps: nsteps < 0");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: no state has been set");
+    if (!h->have_accel)
+        return fail(h, LJMD_ERR_STATE,
+                    "ljmd_enqueue_steps: accelerations not initialised (call ljmd_compute_forces first)");
+    if (h->G != 1)
+        return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: sharded engine; use ljmd_step_begin/finish");
+    static_assert(LJMD_MAX_PENDING_STEPS == kRingCap, "LJMD_MAX_PENDING_STEPS out of sync with the record ring");
+    if ((h->ring_issued - h->ring_consumed) + (unsigned)nsteps > kRingCap)
+        return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: %u + %d pending steps exceed LJMD_MAX_PENDING_STEPS",
+                    h->ring_issued - h->ring_consumed, nsteps);
+    LJMD_HIP(h, hipSetDevice(h->device));
+    for (int s = 0; s < nsteps; ++s) {
+        EventSet *q = next_events(h);
+        int rc_ = enqueue_drift(h, q);
+        if (rc_ != LJMD_OK) return rc_;
+        rc_ = enqueue_forces(h, true, q);
+        if (rc_ != LJMD_OK) return rc_;
+    }
+    return LJMD_OK;
+}
+
+int ljmd_collect_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, double *d_epot, double *dd_epot)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_collect_steps: NULL handle");
+    if (nsteps < 0 || nsteps > (int)kRingCap)
+        return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_collect_steps: nsteps out of range");
+    if (h->G != 1)
+        return fail(h, LJMD_ERR_STATE, "ljmd_collect_steps: sharded engine; use ljmd_read_partials");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    const int rc_ = fetch_ring(h, (unsigned)nsteps);
+    if (rc_ != LJMD_OK) return rc_;
+    for (int s = 0; s < nsteps; ++s)
+        combine_one(h, h->h_ring + (size_t)s * kPartialStride, 1, epot ? epot + s : nullptr,
+                    ekin ? ekin + s : nullptr, d_epot ? d_epot + s : nullptr, dd_epot ? dd_epot + s : nullptr);
+    return LJMD_OK;
+}
+
+int ljmd_snapshot_begin(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_snapshot_begin: NULL handle");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_snapshot_begin: no state has been set");
+    if (h->snap_in_flight)
+        return fail(h, LJMD_ERR_STATE, "ljmd_snapshot_begin: a snapshot is already in flight (call ljmd_snapshot_end)");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    const size_t P3 = 3 * (size_t)h->P * sizeof(double), PI = (size_t)h->P * sizeof(int);
+    if (!h->copy_stream) {
+        LJMD_HIP(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        LJMD_HIP(h, hipEventCreateWithFlags(&h->ev_snap_ready, hipEventDisableTiming));
+        LJMD_HIP(h, hipEventCreateWithFlags(&h->ev_snap_done, hipEventDisableTiming));
+        LJMD_HIP(h, hipMalloc(&h->d_snap, 4 * P3));
+        LJMD_HIP(h, hipMalloc(&h->d_snap_perm, PI));
+        LJMD_HIP(h, hipHostMalloc(&h->h_snap, 4 * P3, hipHostMallocDefault));
+        LJMD_HIP(h, hipHostMalloc(&h->h_snap_perm, PI, hipHostMallocDefault));
+    }
+    // 1. engine stream: freeze the state as of the steps enqueued so far (HBM -> HBM, ~100 N bytes)
+    const double *srcs[4] = {own_block(h), h->d_ru, h->d_v, h->d_a};
+    for (int w = 0; w < 4; ++w)
+        LJMD_HIP(h, hipMemcpyAsync(h->d_snap + (size_t)w * 3 * h->P, srcs[w], P3, hipMemcpyDeviceToDevice, h->stream));
+    LJMD_HIP(h, hipMemcpyAsync(h->d_snap_perm, h->d_perm, PI, hipMemcpyDeviceToDevice, h->stream));
+    LJMD_HIP(h, hipEventRecord(h->ev_snap_ready, h->stream));
+    // 2. copy stream: HBM -> pinned host, concurrent with whatever the engine stream runs next
+    LJMD_HIP(h, hipStreamWaitEvent(h->copy_stream, h->ev_snap_ready, 0));
+    LJMD_HIP(h, hipMemcpyAsync(h->h_snap, h->d_snap, 4 * P3, hipMemcpyDeviceToHost, h->copy_stream));
+    LJMD_HIP(h, hipMemcpyAsync(h->h_snap_perm, h->d_snap_perm, PI, hipMemcpyDeviceToHost, h->copy_stream));
+    LJMD_HIP(h, hipEventRecord(h->ev_snap_done, h->copy_stream));
+    h->snap_in_flight = true;
+    return LJMD_OK;
+}
+
+int ljmd_snapshot_end(ljmd_t *h, double *rx, double *ry, double *rz, double *ux, double *uy, double *uz,
+                      double *vx, double *vy, double *vz, double *ax, double *ay, double *az)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_snapshot_end: NULL handle");
+    if (!h->snap_in_flight) return fail(h, LJMD_ERR_STATE, "ljmd_snapshot_end: no snapshot in flight");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    LJMD_HIP(h, hipEventSynchronize(h->ev_snap_done));      // the transfer only, not the engine's stream
+    h->snap_in_flight = false;
+    const size_t P = h->P;
+    double *dsts[4][3] = {{rx, ry, rz}, {ux, uy, uz}, {vx, vy, vz}, {ax, ay, az}};
+    for (int w = 0; w < 4; ++w)
+        for (int k = 0; k < 3; ++k) {
+            double *dst = dsts[w][k];
+            if (!dst) continue;
+            const double *st = h->h_snap + ((size_t)w * 3 + k) * P;
+            for (size_t i = 0; i < P; ++i) {
+                const int o = h->h_snap_perm[i];
+                if (o < h->S) dst[o] = st[i];              // slot -> original index of the shard
+            }
+        }
     return LJMD_OK;
 }
 

@@ -18,7 +18,12 @@ namespace ljmdk {
 constexpr int kBlock = 256;                 // threads per workgroup = 4 wave64
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kTile = 64;                   // particles per tile = one wave
-constexpr int kRowTiles = 4;                // tiles per Newton-3 row group (particles per lane)
+#ifndef LJMD_ROW_TILES
+#define LJMD_ROW_TILES 4
+#endif
+constexpr int kRowTiles = LJMD_ROW_TILES;   // tiles per Newton-3 row group (particles per lane)
+constexpr unsigned kAllRows = (1u << kRowTiles) - 1u;
+constexpr int kSlotAlign = (kRowTiles * 64 > 256) ? kRowTiles * 64 : 256;   // P is a multiple of this
 constexpr int kPartialStride = 8;           // doubles per per-rank per-step partial record
 constexpr int kFoldBlocks = 128;             // pre-reduction blocks of the scalar partials (large grids)
 constexpr int kBoxStride = 8;               // doubles per tile bounding box (lo xyz, hi xyz, 2 pad)

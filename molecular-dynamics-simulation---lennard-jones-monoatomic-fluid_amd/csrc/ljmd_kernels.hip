@@ -378,10 +378,12 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
     // bounding box of the whole row group (256 particles), wave-uniform, for the image classification
     double glo[3], ghi[3];
     {
-        const double mx[3] = {fmin(fmin(xi[0], xi[1]), fmin(xi[2], xi[3])), fmin(fmin(yi[0], yi[1]), fmin(yi[2], yi[3])),
-                              fmin(fmin(zi[0], zi[1]), fmin(zi[2], zi[3]))};
-        const double Mx[3] = {fmax(fmax(xi[0], xi[1]), fmax(xi[2], xi[3])), fmax(fmax(yi[0], yi[1]), fmax(yi[2], yi[3])),
-                              fmax(fmax(zi[0], zi[1]), fmax(zi[2], zi[3]))};
+        double mx[3] = {xi[0], yi[0], zi[0]}, Mx[3] = {xi[0], yi[0], zi[0]};
+#pragma unroll
+        for (int k = 1; k < kRowTiles; ++k) {
+            mx[0] = fmin(mx[0], xi[k]); mx[1] = fmin(mx[1], yi[k]); mx[2] = fmin(mx[2], zi[k]);
+            Mx[0] = fmax(Mx[0], xi[k]); Mx[1] = fmax(Mx[1], yi[k]); Mx[2] = fmax(Mx[2], zi[k]);
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             glo[k] = __shfl(wave_min(mx[k]), 0, 64);
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
 #define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
     column_tile_loop<NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, mb, a.L, a.invL, a.rc2, sx, sy, \
                                            sz, jx, jy, jz, s12, s6)
-                const bool all4 = mb == 15u;
+                const bool all4 = mb == kAllRows;
                 if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
                 else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
                 else if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
@@ -648,9 +650,9 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
                 fx[k] = fy[k] = fz[k] = 0.0f;
             }
             float jx = 0.0f, jy = 0.0f, jz = 0.0f, t12 = 0.0f, t6 = 0.0f;
-            if (mb == 15u && uni)
+            if (mb == kAllRows && uni)
                 column_loop_f32<true, false>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
-            else if (mb == 15u)
+            else if (mb == kAllRows)
                 column_loop_f32<false, false>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
             else if (uni)
                 column_loop_f32<true, true>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);

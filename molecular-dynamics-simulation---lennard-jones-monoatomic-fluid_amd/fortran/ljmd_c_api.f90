@@ -18,10 +18,12 @@ module ljmd_c_api
   public :: ljmd_create, ljmd_destroy, ljmd_set_state, ljmd_set_accel, ljmd_set_unwrapped
   public :: ljmd_get_state, ljmd_compute_forces, ljmd_verlet_steps, ljmd_kinetic_energy
   public :: ljmd_last_error, ljmd_device_count, ljmd_profile_enable, ljmd_profile_read
+  public :: ljmd_enqueue_steps, ljmd_collect_steps, ljmd_snapshot_begin, ljmd_snapshot_end
   public :: ljmd_check, ljmd_error_text
 
   integer(c_int), parameter, public :: LJMD_OK = 0
   integer(c_int32_t), parameter, public :: LJMD_PRECISION_FP64 = 0
+  integer(c_int32_t), parameter, public :: LJMD_MAX_PENDING_STEPS = 4096
 
   interface
     function ljmd_compute_lj_potential_energy(n, box_length, rc, rx, ry, rz, ax, ay, az, &
@@ -99,6 +101,38 @@ module ljmd_c_api
       type(c_ptr), value :: handle
       integer(c_int32_t), value :: nsteps
       type(c_ptr), value :: epot, ekin, d_epot, dd_epot      ! each c_null_ptr or real(c_double)(nsteps)
+      integer(c_int) :: status
+    end function
+
+    ! asynchronous production loop: enqueue returns at once, collect waits for the engine's stream
+    function ljmd_enqueue_steps(handle, nsteps) bind(C, name="ljmd_enqueue_steps") result(status)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: nsteps
+      integer(c_int) :: status
+    end function
+
+    function ljmd_collect_steps(handle, nsteps, epot, ekin, d_epot, dd_epot) &
+        bind(C, name="ljmd_collect_steps") result(status)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: nsteps
+      type(c_ptr), value :: epot, ekin, d_epot, dd_epot      ! each c_null_ptr or real(c_double)(nsteps)
+      integer(c_int) :: status
+    end function
+
+    ! snapshot of r, ru, v, a: begin = stream-ordered freeze + transfer on a second stream (returns
+    ! at once), end = wait for that transfer only and deliver the arrays
+    function ljmd_snapshot_begin(handle) bind(C, name="ljmd_snapshot_begin") result(status)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int) :: status
+    end function
+
+    function ljmd_snapshot_end(handle, rx, ry, rz, ux, uy, uz, vx, vy, vz, ax, ay, az) &
+        bind(C, name="ljmd_snapshot_end") result(status)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: handle, rx, ry, rz, ux, uy, uz, vx, vy, vz, ax, ay, az
       integer(c_int) :: status
     end function
 

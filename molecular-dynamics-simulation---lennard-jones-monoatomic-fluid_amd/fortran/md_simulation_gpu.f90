@@ -11,7 +11,8 @@
 ! Differences: the state lives in HBM for the whole run (ljmd_verlet_steps advances up to the
 ! next sampling step without touching the host; r, ru, v, a come back only when a snapshot is
 ! written) and the per-step unwrapped-coordinate update (:339-353) happens inside the drift
-! kernel.  Environment: LJMD_DEVICE (default 0).
+! kernel; snapshots leave the GPU through ljmd_snapshot_begin/end while the next steps already run.
+! Environment: LJMD_DEVICE (default 0), LJMD_ASYNC_IO (default 1).
 !==============================================================================
 program md_simulation_gpu
   use, intrinsic :: iso_c_binding
@@ -30,7 +31,8 @@ program md_simulation_gpu
   integer(kind=int_kind) :: total_steps, output_interval, warmup_steps, n_snapshots_expected
   real(kind=dp_kind) :: rc_over_L, target_total_energy
   real(kind=dp_kind) :: epot, ekin, etot, d_epot, dd_epot, time, temp_inst, press_inst, npd
-  integer(kind=int_kind) :: step, next_sample, count, k, num_samples
+  integer(kind=int_kind) :: step, count, k, num_samples
+  logical :: sample_now, async_io
   integer :: iu_rva, iu_out, ios, device
   integer(kind=8) :: c0, c1, crate
   type(c_ptr) :: engine
@@ -46,6 +48,9 @@ program md_simulation_gpu
   device = 0
   call get_environment_variable('LJMD_DEVICE', env, status=ios)
   if (ios == 0 .and. len_trim(env) > 0) read(env, *) device
+  async_io = .true.
+  call get_environment_variable('LJMD_ASYNC_IO', env, status=ios)
+  if (ios == 0 .and. len_trim(env) > 0) async_io = trim(env) /= '0'
 
   call ljmd_check(ljmd_create(engine, params%n, params%box_length, params%dt, params%rc, &
                               LJMD_PRECISION_FP64, int(device, c_int32_t), 0_c_int32_t, 1_c_int32_t), &
@@ -71,42 +76,45 @@ program md_simulation_gpu
   if (ios /= 0) stop 'md_simulation: cannot open outputs/one_run/instantaneous_energies.dat'
   write(iu_out, '(a)') '# time   epot   ekin   etot   T   P'
 
-  allocate(s_epot(output_interval + warmup_steps + 1), s_ekin(output_interval + warmup_steps + 1), &
-           s_depot(output_interval + warmup_steps + 1), s_ddepot(output_interval + warmup_steps + 1))
+  allocate(s_epot(LJMD_MAX_PENDING_STEPS), s_ekin(LJMD_MAX_PENDING_STEPS), &
+           s_depot(LJMD_MAX_PENDING_STEPS), s_ddepot(LJMD_MAX_PENDING_STEPS))
   npd = dble(params%n)
   call stats_begin(stats, params%n, params%volume, n_snapshots_expected)
   num_samples = 0
   step = 0
   call system_clock(c0, crate)
+  ! Software pipeline: while the host formats and writes the sample taken at step s, the GPU is
+  ! already running the steps up to the next sampling instant.  LJMD_ASYNC_IO=0 serialises the two
+  ! (the next segment is enqueued only after the files are written) for A/B timing.
+  count = segment_length(step)
+  call ljmd_check(ljmd_enqueue_steps(engine, count), engine, 'ljmd_enqueue_steps')
   do while (step < total_steps)
-    ! first step > `step` that satisfies the sampling condition of :361
-    next_sample = (step / output_interval + 1) * output_interval
-    do while (next_sample <= warmup_steps)
-      next_sample = next_sample + output_interval
-    end do
-    next_sample = min(next_sample, total_steps)
-    count = next_sample - step
-    call ljmd_check(ljmd_verlet_steps(engine, count, c_loc(s_epot), c_loc(s_ekin), c_loc(s_depot), &
-                                      c_loc(s_ddepot)), engine, 'ljmd_verlet_steps')
+    call ljmd_check(ljmd_collect_steps(engine, count, c_loc(s_epot), c_loc(s_ekin), c_loc(s_depot), &
+                                       c_loc(s_ddepot)), engine, 'ljmd_collect_steps')
     do k = 1, count
       time = time + params%dt                       ! accumulated as at :356
     end do
-    step = next_sample
+    step = step + count
     epot = s_epot(count); ekin = s_ekin(count); d_epot = s_depot(count); dd_epot = s_ddepot(count)
     etot = epot + ekin
-    if (step > warmup_steps .and. mod(step, output_interval) == 0) then
+    sample_now = step > warmup_steps .and. mod(step, output_interval) == 0       ! :361
+    if (sample_now) call ljmd_check(ljmd_snapshot_begin(engine), engine, 'ljmd_snapshot_begin')
+    count = segment_length(step)
+    if (async_io .and. count > 0) call ljmd_check(ljmd_enqueue_steps(engine, count), engine, 'ljmd_enqueue_steps')
+    if (sample_now) then
       num_samples = num_samples + 1
       call stats_push(stats, epot, ekin, d_epot, dd_epot, temp_inst, press_inst)   ! T, P as md_means.f90:221,227
       write(iu_out, '(1pe13.6,5(2x,1pe13.6))') time, epot, ekin, etot, temp_inst, press_inst
-      call ljmd_check(ljmd_get_state(engine, c_loc(state%rx), c_loc(state%ry), c_loc(state%rz), &
-                                     c_loc(rux), c_loc(ruy), c_loc(ruz), &
-                                     c_loc(state%vx), c_loc(state%vy), c_loc(state%vz), &
-                                     c_loc(state%ax), c_loc(state%ay), c_loc(state%az)), engine, 'ljmd_get_state')
+      call ljmd_check(ljmd_snapshot_end(engine, c_loc(state%rx), c_loc(state%ry), c_loc(state%rz), &
+                                        c_loc(rux), c_loc(ruy), c_loc(ruz), &
+                                        c_loc(state%vx), c_loc(state%vy), c_loc(state%vz), &
+                                        c_loc(state%ax), c_loc(state%ay), c_loc(state%az)), engine, 'ljmd_snapshot_end')
       write(iu_rva) state%rx, state%ry, state%rz
       write(iu_rva) rux, ruy, ruz
       write(iu_rva) state%vx, state%vy, state%vz
       write(iu_rva) state%ax, state%ay, state%az
     end if
+    if (.not. async_io .and. count > 0) call ljmd_check(ljmd_enqueue_steps(engine, count), engine, 'ljmd_enqueue_steps')
   end do
   call system_clock(c1)
   close(iu_out)
@@ -120,6 +128,19 @@ program md_simulation_gpu
     0.5d0 * npd * (npd - 1.d0) * dble(total_steps) * dble(crate) / dble(max(c1 - c0, 1_8)), ' pair-interactions/s'
 
 contains
+
+  ! steps from `from_step` to the next sampling instant of :361 (or to the end of the run), capped by
+  ! the engine's pending-step limit; 0 when the run is complete
+  function segment_length(from_step) result(n)
+    integer(kind=int_kind), intent(in) :: from_step
+    integer(kind=int_kind) :: n, nxt
+    nxt = (from_step / output_interval + 1) * output_interval
+    do while (nxt <= warmup_steps)
+      nxt = nxt + output_interval
+    end do
+    nxt = min(nxt, total_steps)
+    n = min(max(nxt - from_step, 0), LJMD_MAX_PENDING_STEPS)
+  end function segment_length
 
   ! outputs/rv_init.dat: record 1 = rx ry rz, record 2 = vx vy vz (md_initial_config_program.f90:285-286)
   subroutine read_rv_init(filename)

@@ -165,6 +165,25 @@ class Engine:
         self._ck(self._lib.ljmd_verlet_steps(self._h, nsteps, *[_ptr(o) for o in outs]))
         return tuple(outs)
 
+    # -- asynchronous production loop (snapshot I/O overlapped with the next steps) --------
+    def enqueue_steps(self, nsteps: int) -> None:
+        self._ck(self._lib.ljmd_enqueue_steps(self._h, nsteps))
+
+    def collect_steps(self, nsteps: int):
+        outs = [np.empty(nsteps, dtype=np.float64) for _ in range(4)]
+        self._ck(self._lib.ljmd_collect_steps(self._h, nsteps, *[_ptr(o) for o in outs]))
+        return tuple(outs)
+
+    def snapshot_begin(self) -> None:
+        self._ck(self._lib.ljmd_snapshot_begin(self._h))
+
+    def snapshot_end(self) -> dict:
+        """-> {'r': (x,y,z), 'ru': ..., 'v': ..., 'a': ...} as of the matching snapshot_begin."""
+        out = {key: tuple(np.empty(self.shard, dtype=np.float64) for _ in range(3)) for key in ("r", "ru", "v", "a")}
+        ptrs = [_ptr(a) for key in ("r", "ru", "v", "a") for a in out[key]]
+        self._ck(self._lib.ljmd_snapshot_end(self._h, *ptrs))
+        return out
+
     def kinetic_energy(self) -> float:
         k = C.c_double()
         self._ck(self._lib.ljmd_kinetic_energy(self._h, C.byref(k)))

@@ -4,9 +4,10 @@ touches the hot path -- parameter + rv_init input, t=0 forces, the MD loop, the 
 condition, instantaneous_energies.dat and rva.dat output -- plus the end-of-run statistics
 files (:401-560) through `stats`.
 
-Between two sampling steps the state never leaves HBM: the loop advances
-`steps until next sample` with one ljmd_verlet_steps call and reads r/ru/v/a back only
-when a snapshot is due.
+Between two sampling steps the state never leaves HBM, and the host's sample I/O is
+pipelined against the GPU: at a sampling step the state is frozen on the device
+(`snapshot_begin`), the next segment of steps is enqueued at once, and only then does the
+host wait for the snapshot transfer and write the files.
 """
 from __future__ import annotations
 
@@ -18,6 +19,8 @@ import numpy as np
 from . import io_formats, stats
 from .physics import Engine
 from .read_input_files import RunControl, read_simulation_parameters
+
+MAX_PENDING_STEPS = 4096      # LJMD_MAX_PENDING_STEPS (include/ljmd.h)
 
 
 @dataclass
@@ -61,18 +64,28 @@ def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunR
         t = 0.0
         step = 0
         t0 = _time.perf_counter()
-        while step < ctl.total_steps:
-            # next sampling step strictly after `step` (condition of :361)
-            nxt = (step // ctl.output_interval + 1) * ctl.output_interval
+        def segment_length(from_step: int) -> int:
+            """steps to the next sampling instant of :361 (or the end), capped by the pending-step limit"""
+            nxt = (from_step // ctl.output_interval + 1) * ctl.output_interval
             while nxt <= ctl.warmup_steps:
                 nxt += ctl.output_interval
-            nxt = min(nxt, ctl.total_steps)
-            count = nxt - step
-            epot, ekin, d_epot, dd_epot = eng.verlet_steps(count)
+            return min(max(min(nxt, ctl.total_steps) - from_step, 0), MAX_PENDING_STEPS)
+
+        # software pipeline: the GPU runs the next segment while the host writes this sample
+        count = segment_length(step)
+        eng.enqueue_steps(count)
+        while step < ctl.total_steps:
+            epot, ekin, d_epot, dd_epot = eng.collect_steps(count)
             for _ in range(count):
                 t = t + p.dt                                      # :356 accumulated, not step*dt
-            step = nxt
-            if step > ctl.warmup_steps and step % ctl.output_interval == 0:
+            step += count
+            sample_now = step > ctl.warmup_steps and step % ctl.output_interval == 0
+            if sample_now and rva is not None:
+                eng.snapshot_begin()
+            count = segment_length(step)
+            if count > 0:
+                eng.enqueue_steps(count)
+            if sample_now:
                 e, k = float(epot[-1]), float(ekin[-1])
                 temp, press = acc.push(e, k, d_epot[-1], dd_epot[-1])                   # :371-372
                 etot = e + k
@@ -82,7 +95,7 @@ def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunR
                                  (res.temp, temp), (res.press, press)):
                     lst.append(val)
                 if rva is not None:
-                    st = eng.get_state()
+                    st = eng.snapshot_end()
                     rva.write_snapshot(st["r"], st["ru"], st["v"], st["a"])           # :384-387
         res.steps_per_second = ctl.total_steps / max(_time.perf_counter() - t0, 1e-12)
         f_en.close()

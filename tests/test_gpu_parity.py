@@ -494,3 +494,65 @@ def test_production_loop_files_vs_reference(tmp_path, golden):
     assert h1 == h2 and s1.shape == s2.shape == (9, 4, 3, 108)
     assert (tmp_path / "outputs" / "one_run" / "rva.dat").stat().st_size == (src / "rva.dat").stat().st_size
     assert np.abs(s1[0] - s2[0]).max() < 1e-9          # first snapshot (step 200): inside the horizon
+
+
+def test_async_steps_and_snapshot_equal_the_synchronous_path(golden):
+    """ljmd_enqueue_steps/collect_steps + ljmd_snapshot_begin/end (the pipelined production loop) against
+    ljmd_verlet_steps + ljmd_get_state: same kernels, same order -> bitwise equal scalars and arrays, even
+    though 45 further steps (two re-sorts) are enqueued between snapshot_begin and snapshot_end."""
+    g = golden("traj_n4096_200")
+    p = init_params(4096, float(g["L"]), float(g["dt"]), float(g["rc"]))
+    r0, v0 = g["r0"], g["v0"]
+    with Engine(p) as ref:
+        ref.set_state(r0[0], r0[1], r0[2], v0[0], v0[1], v0[2])
+        ref.compute_forces()
+        sc_a = ref.verlet_steps(30)
+        st_a = ref.get_state()
+        sc_b = ref.verlet_steps(45)
+        st_b = ref.get_state()
+    with Engine(p) as eng:
+        eng.set_state(r0[0], r0[1], r0[2], v0[0], v0[1], v0[2])
+        eng.compute_forces()
+        eng.enqueue_steps(30)
+        got_a = eng.collect_steps(30)
+        eng.snapshot_begin()
+        eng.enqueue_steps(45)                       # runs while the snapshot is in flight
+        snap = eng.snapshot_end()
+        got_b = eng.collect_steps(45)
+        fin = eng.get_state()
+    for x, y in zip(sc_a + sc_b, got_a + got_b):
+        assert np.array_equal(x, y)
+    for key in ("r", "ru", "v", "a"):
+        assert np.array_equal(np.stack(snap[key]), np.stack(st_a[key])), key
+        assert np.array_equal(np.stack(fin[key]), np.stack(st_b[key])), key
+
+
+def test_async_api_sequence_errors():
+    p = init_params(256, 8.0, 0.005, 3.0)
+    z = np.linspace(0.1, 7.9, 256)
+    with Engine(p) as eng:
+        with pytest.raises(ljmd_amd.LjmdError) as e:
+            eng.snapshot_begin()                                   # no state yet
+        assert e.value.code == -4
+        eng.set_state(z, z[::-1].copy(), np.roll(z, 5), z * 0, z * 0, z * 0)
+        with pytest.raises(ljmd_amd.LjmdError):
+            eng.enqueue_steps(1)                                   # no accelerations yet
+        eng.compute_forces()
+        with pytest.raises(ljmd_amd.LjmdError) as e:
+            eng.snapshot_end()                                     # nothing in flight
+        assert e.value.code == -4
+        eng.snapshot_begin()
+        with pytest.raises(ljmd_amd.LjmdError) as e:
+            eng.snapshot_begin()                                   # one snapshot at a time
+        assert e.value.code == -4
+        st = eng.snapshot_end()
+        assert np.array_equal(st["r"][0], z)
+        eng.enqueue_steps(4096)                                    # LJMD_MAX_PENDING_STEPS
+        with pytest.raises(ljmd_amd.LjmdError) as e:
+            eng.enqueue_steps(1)                                   # record ring would overflow
+        assert e.value.code == -4
+        with pytest.raises(ljmd_amd.LjmdError):
+            eng.collect_steps(4097)
+        assert eng.collect_steps(3)[0].shape == (3,)               # the last 3 of the 4096; older ones dropped
+        eng.enqueue_steps(2)
+        assert eng.collect_steps(2)[1].shape == (2,)
