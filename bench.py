@@ -30,6 +30,7 @@ if str(ROOT) not in sys.path:
 N_PARTICLES = 262144
 FLOP_PER_UNORDERED_PAIR = 33.8   # reference's Newton-3 loop: 21 outside + 0.493 * 26 inside the cutoff
 FP64_VALU_PEAK_TFLOPS = 78.6     # MI355X vector fp64 (256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz / 2)
+HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E (MI355X_MICROARCH.md)
 
 
 def cpu_baseline(budget_s: float = 20.0) -> dict:
@@ -75,16 +76,15 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
     import torch
-    # torch bundles its own ROCm 7.0 runtime (libamdhip64.so + libhsa-runtime64.so under torch/lib) next
-    # to the system ROCm 7.2 runtime that libljmd.so and RCCL link, so `torch.cuda.synchronize()` acts on a
-    # HIP runtime that never sees this program's kernels.  Single GPU: it is initialised FIRST (the order
-    # that is known to coexist) and called beside the real synchronisation, as the bench contract words
-    # it.  Multi GPU: torch's runtime is deliberately never initialised -- a second HSA instance per
-    # process next to RCCL's IPC setup is a risk with no benefit -- and the bracket is
-    # gloo barrier + hipStreamSynchronize/hipDeviceSynchronize on the engine's device (Engine.synchronize).
-    torch_gpu = world == 1 and torch.cuda.is_available()
+    # HIP runtime bookkeeping: torch ships its own libamdhip64 / librccl / libhsa-runtime64 (same SONAMEs as
+    # the system ROCm ones).  torch is imported FIRST here, so when libljmd.so is loaded next the dynamic
+    # loader resolves its NEEDED libamdhip64.so.7 / librccl.so.1 to the copies torch already mapped: ONE HIP
+    # runtime and ONE RCCL per process, shared by torch and the engine (checked via /proc/self/maps), and
+    # `torch.cuda.synchronize()` below really covers the engine's kernels.  The engine's own
+    # hipStreamSynchronize + hipDeviceSynchronize (Engine.synchronize) is called beside it anyway.
+    torch_gpu = torch.cuda.is_available()
     if torch_gpu:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(0 if os.environ.get("LJMD_BENCH_SHARE_DEVICE", "0") == "1" else local_rank)
     import ljmd_amd  # noqa: F401
     from ljmd_amd import Engine, synthetic, distributed
 
@@ -112,7 +112,7 @@ def main() -> None:
     def barrier():
         eng.synchronize()                    # hipStreamSynchronize + hipDeviceSynchronize on the engine's device
         if torch_gpu:
-            torch.cuda.synchronize(local_rank)
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             eng.synchronize()
@@ -172,6 +172,14 @@ def main() -> None:
             "energy_check": {"etot_first": float(etot[0]), "etot_last": float(etot[-1]),
                              "rel_drift": float(abs(etot[-1] - etot[0]) / abs(etot[0]))},
         }
+        # the HBM-bound kernel of the step, K1 (drift + wrap + half-kick + unwrapped update): 168 N algorithmic
+        # bytes per launch / its shortest HIP-event interval (= K1 alone; steps that re-sort are longer)
+        if prof.get("drift_ms_min", 0.0) > 0.0:
+            k1_gbps = (168.0 * n / world) / (prof["drift_ms_min"] * 1e-3) / 1e9
+            line["roofline_hbm_kernel"] = {"kernel": "drift_kick_kernel", "bound": "hbm", "achieved": k1_gbps,
+                                           "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": k1_gbps / HBM_PEAK_GBPS,
+                                           "kernel_ms_min": prof["drift_ms_min"],
+                                           "algorithmic_bytes": 168.0 * n / world}
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
         # command (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be read from inside the run)
         pmc = ROOT / "profiles" / "r01_final_pmc_hbm_traffic.json"

@@ -264,6 +264,9 @@ int ljmd_profile_enable(ljmd_t *h, int32_t on);
 /* Name of the pair-force kernel the next force evaluation will launch (for profile matching). */
 const char *ljmd_pair_kernel_name(const ljmd_t *h);
 int ljmd_profile_read(ljmd_t *h, double *ms_avg /* [4] */, int32_t *launches);
+/* Same, plus the minimum over the launches of each interval (ms_min[2] = the drift/kick kernel alone:
+ * the steps that also re-sort are longer).  Either array may be NULL. */
+int ljmd_profile_read_ex(ljmd_t *h, double *ms_avg /* [4] */, double *ms_min /* [4] */, int32_t *launches);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "ljmd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "ljmd_pair_kernel_name": (C.c_char_p, [C.c_void_p]),
     "ljmd_profile_read": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
+    "ljmd_profile_read_ex": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p]),
 }
 
 _lib = None

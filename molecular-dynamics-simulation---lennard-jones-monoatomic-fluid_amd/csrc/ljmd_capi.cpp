@@ -58,6 +58,7 @@ struct ljmd {
     bool have_state = false, have_accel = false;
     bool sort_enabled = true;
     bool force_generic = false;       // LJMD_FORCE_GENERIC=1: always take the exact generic kernel (A/B tests)
+    bool force_collectives = false;   // LJMD_FORCE_COLLECTIVES=1: a 1-rank engine still issues its RCCL calls (tests)
     int resort_every = 20, steps_since_sort = 0, ncell = 1;
 
     hipStream_t stream = nullptr;
@@ -226,7 +227,7 @@ N3Args n3_args(ljmd_t *h)
     return a;
 }
 
-bool needs_force_exchange(const ljmd_t *h) { return h->use_n3 && h->G > 1; }
+bool needs_force_exchange(const ljmd_t *h) { return h->use_n3 && (h->G > 1 || h->force_collectives); }
 
 IntegrateArgs integrate_args(ljmd_t *h)
 {
@@ -609,6 +610,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     // below ~16 tiles there is nothing for the tile mask to skip: keep the caller's order
     h->sort_enabled = env_int("LJMD_SORT", 1) != 0 && n >= env_int("LJMD_SORT_MIN_N", 1024);
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
+    h->force_collectives = env_int("LJMD_FORCE_COLLECTIVES", 0) != 0;
     h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", 20));
     h->ncell = std::max(1, std::min(1023, (int)std::floor(box_length / 1.2)));
     h->kd_sort = env_int("LJMD_SORT_KD", 1) != 0;
@@ -1174,7 +1176,7 @@ int ljmd_comm_init(ljmd_t *h, const char *id)
 int ljmd_allgather_positions(ljmd_t *h)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_allgather_positions: NULL handle");
-    if (h->G == 1) return LJMD_OK;
+    if (h->G == 1 && !h->force_collectives) return LJMD_OK;
     if (!h->comm) return fail(h, LJMD_ERR_STATE, "ljmd_allgather_positions: call ljmd_comm_init first");
     LJMD_HIP(h, hipSetDevice(h->device));
     // in place: the send block is this rank's slice of the receive buffer; enqueued on the engine's
@@ -1226,10 +1228,16 @@ int ljmd_profile_enable(ljmd_t *h, int32_t on)
 
 int ljmd_profile_read(ljmd_t *h, double *ms_avg, int32_t *launches)
 {
+    return ljmd_profile_read_ex(h, ms_avg, nullptr, launches);
+}
+
+int ljmd_profile_read_ex(ljmd_t *h, double *ms_avg, double *ms_min, int32_t *launches)
+{
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_read: NULL handle");
     LJMD_HIP(h, hipSetDevice(h->device));
     LJMD_HIP(h, hipStreamSynchronize(h->stream));
     double acc[4] = {0, 0, 0, 0};  // pair kernel, geometry pre-pass, drift/kick, reduce+finalize
+    double lo[4] = {1e300, 1e300, 1e300, 1e300};
     const int from[4] = {2, 1, 0, 3}, to[4] = {3, 2, 1, 4};
     size_t complete = 0;
     for (size_t k = 0; k < h->ev_used; ++k) {
@@ -1244,13 +1252,18 @@ int ljmd_profile_read(ljmd_t *h, double *ms_avg, int32_t *launches)
             (void)hipGetLastError();
             continue;
         }
-        for (int c = 0; c < 4; ++c) acc[c] += one[c];
+        for (int c = 0; c < 4; ++c) {
+            acc[c] += one[c];
+            lo[c] = std::min(lo[c], one[c]);
+        }
         ++complete;
     }
     h->ev_used = complete;
     const double cnt = h->ev_used ? (double)h->ev_used : 1.0;
     if (ms_avg)
         for (int c = 0; c < 4; ++c) ms_avg[c] = acc[c] / cnt;
+    if (ms_min)
+        for (int c = 0; c < 4; ++c) ms_min[c] = h->ev_used ? lo[c] : 0.0;
     if (launches) *launches = (int32_t)h->ev_used;
     h->ev_used = 0;
     return LJMD_OK;

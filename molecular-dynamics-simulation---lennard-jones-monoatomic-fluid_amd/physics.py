@@ -267,12 +267,14 @@ class Engine:
         return self._lib.ljmd_pair_kernel_name(self._h).decode()
 
     def profile_read(self) -> dict:
-        """-> {'pair_ms', 'geometry_ms', 'drift_ms', 'reduce_ms', 'launches'} averages per launch"""
-        ms = (C.c_double * 4)()
+        """-> {'pair_ms', 'geometry_ms', 'drift_ms', 'reduce_ms', 'launches'} averages per launch,
+        plus '<name>_min': the shortest launch of each interval"""
+        ms, lo = (C.c_double * 4)(), (C.c_double * 4)()
         c = C.c_int32()
-        self._ck(self._lib.ljmd_profile_read(self._h, ms, C.byref(c)))
-        return {"pair_ms": ms[0], "geometry_ms": ms[1], "drift_ms": ms[2], "reduce_ms": ms[3],
-                "launches": c.value}
+        self._ck(self._lib.ljmd_profile_read_ex(self._h, ms, lo, C.byref(c)))
+        out = {"pair_ms": ms[0], "geometry_ms": ms[1], "drift_ms": ms[2], "reduce_ms": ms[3], "launches": c.value}
+        out.update({"pair_ms_min": lo[0], "geometry_ms_min": lo[1], "drift_ms_min": lo[2], "reduce_ms_min": lo[3]})
+        return out
 
 
 def observables(params: SimParams, epot: float, ekin: float, d_epot: float):

@@ -137,6 +137,43 @@ def test_rccl_communicator_single_rank():
         assert np.array_equal(np.stack(sc), np.stack(ref.verlet_steps(5)))
 
 
+def test_rccl_collectives_really_issued_on_the_engine_stream(monkeypatch):
+    """LJMD_FORCE_COLLECTIVES=1: a 1-rank engine goes through the multi-rank code path for real --
+    ncclAllGather (in place) between the drift kernel and the pair kernel, ncclReduceScatter of the
+    partial accelerations into the receive buffer the kick kernel reads -- both enqueued by the library
+    on its own non-blocking stream with no host synchronisation.  RCCL refuses two ranks on one device,
+    so the communicator has one rank; everything else (buffers, stream order, kernels) is the G > 1 path.
+    The trajectory must equal the plain single-GPU one bit for bit."""
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+    p, r, v = synthetic.make_config(16384, seed=3)
+    with Engine(p) as ref:
+        ref.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e_ref = ref.compute_forces()
+        sc_ref = ref.verlet_steps(25)                    # crosses a re-sort
+        st_ref = ref.get_state()
+    monkeypatch.setenv("LJMD_FORCE_COLLECTIVES", "1")
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        with pytest.raises(ljmd_amd.LjmdError, match="ljmd_comm_init"):
+            eng.forces_partial()                         # collectives demanded, no communicator yet
+        eng.comm_init(Engine.comm_unique_id())
+        eng.allgather_positions()
+        eng.forces_partial()                             # pair kernel -> reduce -> ncclReduceScatter -> x24
+        rec0 = eng.read_partials(1)
+        e0 = eng.combine_scalars(rec0)
+        assert (e0[0], e0[2], e0[3]) == e_ref
+        for _ in range(25):
+            eng.step_begin()
+            eng.allgather_positions()
+            eng.step_finish()
+        recs = eng.read_partials(25)
+        sc = [eng.combine_scalars(recs[k:k + 1]) for k in range(25)]
+        st = eng.get_state()
+    assert np.array_equal(np.array(sc).T, np.stack(sc_ref))
+    for key in ("r", "ru", "v", "a"):
+        assert np.array_equal(np.stack(st[key]), np.stack(st_ref[key])), key
+
+
 def test_bench_two_processes_host_staged_exchange(tmp_path):
     """bench.py end to end with TWO processes (torch.distributed.run, gloo control plane) sharing this
     box's single GPU; the exchange is the host-staged safety net because RCCL refuses two ranks on one
