@@ -60,6 +60,41 @@ def cpu_baseline(budget_s: float = 20.0) -> dict:
                              f"(the O(N) integrator is <0.1% of a CPU step)"}
 
 
+def host_cpu_share() -> int:
+    """Cores this process may actually use: min(visible CPUs, cgroup CPU quota)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline_all_cores(rows: int = 16384) -> dict:
+    """the C oracle's OpenMP full-matrix form (every ordered pair, same per-pair arithmetic as
+    the reference loop, no Newton-3 scatter so that rows are independent) on this box's CPU share, on a bounded
+    sample of the bench workload: the first `rows` rows of the N = 262144 pair matrix against all columns."""
+    cores = host_cpu_share()
+    os.environ["OMP_NUM_THREADS"] = str(cores)          # before liboracle.so (libgomp) is loaded
+    from oracle import oracle as O
+    from ljmd_amd import synthetic
+    p, r, _ = synthetic.make_config(N_PARTICLES)
+    po = O.derive_params(p.n, p.box_length, p.dt, p.rc)
+    x, y, z = (np.ascontiguousarray(a) for a in r)
+    O.rows_raw(po, 0, 256, x, y, z)                      # thread-pool warm-up
+    t0 = time.perf_counter()
+    O.rows_raw(po, 0, rows, x, y, z)
+    secs = time.perf_counter() - t0
+    step_s = secs * N_PARTICLES / rows
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "ordered_pairs_per_s": rows * (N_PARTICLES - 1) / secs, "seconds": secs,
+            "sample": f"C oracle, OpenMP full-matrix rows (gcc -O2, no FMA), rows 0..{rows - 1} of the N={N_PARTICLES} "
+                      f"bench configuration against all columns on {cores} threads (cgroup CPU share of "
+                      f"{os.cpu_count()} visible CPUs); one force evaluation = {N_PARTICLES // rows}x the sample"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +229,11 @@ def main() -> None:
             except Exception as exc:  # the baseline is a reported number, never a reason to lose the bench line
                 line["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {exc}"}
+            try:
+                line["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+            except Exception as exc:
+                line["cpu_baseline_all_cores"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port",
+                                                  "sample": f"failed: {exc}"}
         print(json.dumps(line), flush=True)
 
     eng.close()
