@@ -63,6 +63,12 @@ struct ljmd {
 
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;        // RCCL communicator over the G ranks (multi-GPU only)
+    // position all-gather overlapped with the velocity half-kick: the collective runs on comm_stream between
+    // ev_pos_ready (positions drifted, engine stream) and ev_gather_done (awaited by the engine stream)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_pos_ready = nullptr, ev_gather_done = nullptr;
+    bool overlap_exchange = true;     // LJMD_OVERLAP_EXCHANGE
+    bool gather_done_for_step = false;
     // ---- HBM-resident state (layout: ljmd_internal.h) ----
     double *d_pos = nullptr;      // [G][3][P] exchange buffer (all positions)
     double *d_ru = nullptr, *d_v = nullptr, *d_a = nullptr;   // [3][P]
@@ -431,10 +437,36 @@ int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
     return rc_ != LJMD_OK ? rc_ : enqueue_kick(h, kick, q);
 }
 
+int allgather_on(ljmd_t *h, hipStream_t s)
+{
+    // in place: the send block is this rank's slice of the receive buffer
+    const ncclResult_t r = ncclAllGather(own_block(h), h->d_pos, 3 * (size_t)h->P, ncclDouble, h->comm, s);
+    if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+    return LJMD_OK;
+}
+
 int enqueue_drift(ljmd_t *h, EventSet *q)
 {
     if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
-    LJMD_HIP(h, launch_drift_kick(integrate_args(h), h->stream));
+    h->gather_done_for_step = false;
+    const bool resort_now = h->sort_enabled && fast_path_ok(h) && h->steps_since_sort + 1 >= h->resort_every;
+    const bool collectives = h->comm && (h->G > 1 || h->force_collectives);
+    if (collectives && h->overlap_exchange && !resort_now) {
+        // positions first; the all-gather starts on the communication stream as soon as they are final and
+        // overlaps the velocity half-kick; the engine's stream resumes (geometry pre-pass, pair kernel) when
+        // the gathered positions have arrived.  (Re-sort steps permute the block after K1: serial path below.)
+        LJMD_HIP(h, launch_drift_kick(integrate_args(h), 1, h->stream));
+        LJMD_HIP(h, hipEventRecord(h->ev_pos_ready, h->stream));
+        LJMD_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_pos_ready, 0));
+        const int rc_ = allgather_on(h, h->comm_stream);
+        if (rc_ != LJMD_OK) return rc_;
+        LJMD_HIP(h, hipEventRecord(h->ev_gather_done, h->comm_stream));
+        LJMD_HIP(h, launch_drift_kick(integrate_args(h), 2, h->stream));
+        LJMD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gather_done, 0));
+        h->gather_done_for_step = true;
+    } else {
+        LJMD_HIP(h, launch_drift_kick(integrate_args(h), 0, h->stream));
+    }
     h->positions_compact = true;  // freshly wrapped into [0, L]
     if (h->sort_enabled && fast_path_ok(h) && ++h->steps_since_sort >= h->resort_every)
         return resort(h, false);  // a(t) is dead after the drift/kick: K3 rewrites it
@@ -487,7 +519,11 @@ void release(ljmd_t *h)
     if (!h) return;
     if (h->device >= 0) (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->ev_pos_ready) (void)hipEventDestroy(h->ev_pos_ready);
+    if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
     for (auto &q : h->ev_pool)
         for (auto &e : q.e) (void)hipEventDestroy(e);
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
@@ -1170,6 +1206,10 @@ int ljmd_comm_init(ljmd_t *h, const char *id)
         h->comm = nullptr;
         return fail(h, LJMD_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", h->rank, h->G, ncclGetErrorString(r));
     }
+    h->overlap_exchange = env_int("LJMD_OVERLAP_EXCHANGE", 1) != 0;
+    LJMD_HIP(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    LJMD_HIP(h, hipEventCreateWithFlags(&h->ev_pos_ready, hipEventDisableTiming));
+    LJMD_HIP(h, hipEventCreateWithFlags(&h->ev_gather_done, hipEventDisableTiming));
     return LJMD_OK;
 }
 
@@ -1179,12 +1219,13 @@ int ljmd_allgather_positions(ljmd_t *h)
     if (h->G == 1 && !h->force_collectives) return LJMD_OK;
     if (!h->comm) return fail(h, LJMD_ERR_STATE, "ljmd_allgather_positions: call ljmd_comm_init first");
     LJMD_HIP(h, hipSetDevice(h->device));
-    // in place: the send block is this rank's slice of the receive buffer; enqueued on the engine's
-    // stream, i.e. behind the drift/kick (and re-sort) kernels and ahead of the pair kernel
-    const size_t count = 3 * (size_t)h->P;
-    const ncclResult_t r = ncclAllGather(own_block(h), h->d_pos, count, ncclDouble, h->comm, h->stream);
-    if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
-    return LJMD_OK;
+    if (h->gather_done_for_step) {       // already issued by ljmd_step_begin on the communication stream
+        h->gather_done_for_step = false;
+        return LJMD_OK;
+    }
+    // serial form (t = 0, re-sort steps, LJMD_OVERLAP_EXCHANGE=0): on the engine's stream, i.e. behind the
+    // drift/kick (and re-sort) kernels and ahead of the pair kernel
+    return allgather_on(h, h->stream);
 }
 
 int ljmd_memcpy(ljmd_t *h, void *dst, const void *src, int64_t bytes, int32_t kind)

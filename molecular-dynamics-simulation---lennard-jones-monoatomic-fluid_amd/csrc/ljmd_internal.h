@@ -128,7 +128,7 @@ hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s)
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s);
 hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s);
-hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s);
+hipError_t launch_drift_kick(const IntegrateArgs &a, int phase /* 0 all, 1 positions, 2 velocities */, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);
 hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);

@@ -774,6 +774,10 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
 //   ru = ru + mic(r_new - r_old)              md_simulation_program.f90:341-351 (dnint)
 // HBM-bound: reads r,v,a,ru (96 B) + writes r,v,ru (72 B) = 168 B per particle.
 // ---------------------------------------------------------------------------
+// PHASE 0: everything.  Multi-rank runs split it so that the position all-gather can start as early as
+// possible: PHASE 1 = positions (r, wrap, ru), PHASE 2 = the velocity half-kick, which then runs
+// while the all-gather is in flight on the communication stream.  Same arithmetic either way.
+template <int PHASE>
 __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -781,14 +785,17 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         const size_t o = (size_t)ax * a.P + i;
-        const double r0 = a.r[o], v0 = a.v[o], acc = a.a[o];
-        double r1 = (r0 + v0 * a.dt) + acc * a.dt_sq_half;
-        r1 = r1 - a.L * __builtin_floor(r1 * a.invL);
-        double d = r1 - r0;
-        d = d - a.L * __builtin_round(d * a.invL);
-        a.r[o] = r1;
-        a.v[o] = v0 + acc * a.dt_half;
-        a.ru[o] = a.ru[o] + d;
+        const double v0 = a.v[o], acc = a.a[o];
+        if constexpr (PHASE != 2) {
+            const double r0 = a.r[o];
+            double r1 = (r0 + v0 * a.dt) + acc * a.dt_sq_half;
+            r1 = r1 - a.L * __builtin_floor(r1 * a.invL);
+            double d = r1 - r0;
+            d = d - a.L * __builtin_round(d * a.invL);
+            a.r[o] = r1;
+            a.ru[o] = a.ru[o] + d;
+        }
+        if constexpr (PHASE != 1) a.v[o] = v0 + acc * a.dt_half;
     }
 }
 
@@ -1047,9 +1054,15 @@ hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_drift_kick(const IntegrateArgs &a, hipStream_t s)
+hipError_t launch_drift_kick(const IntegrateArgs &a, int phase, hipStream_t s)
 {
-    hipLaunchKernelGGL(drift_kick_kernel, dim3((a.rows + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    const dim3 grid((a.rows + kBlock - 1) / kBlock);
+    if (phase == 1)
+        hipLaunchKernelGGL(drift_kick_kernel<1>, grid, dim3(kBlock), 0, s, a);
+    else if (phase == 2)
+        hipLaunchKernelGGL(drift_kick_kernel<2>, grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(drift_kick_kernel<0>, grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

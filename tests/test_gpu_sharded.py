@@ -137,11 +137,14 @@ def test_rccl_communicator_single_rank():
         assert np.array_equal(np.stack(sc), np.stack(ref.verlet_steps(5)))
 
 
-def test_rccl_collectives_really_issued_on_the_engine_stream(monkeypatch):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_rccl_collectives_really_issued_by_the_engine(monkeypatch, overlap):
     """LJMD_FORCE_COLLECTIVES=1: a 1-rank engine goes through the multi-rank code path for real --
-    ncclAllGather (in place) between the drift kernel and the pair kernel, ncclReduceScatter of the
+    ncclAllGather (in place) between the position update and the pair kernel, ncclReduceScatter of the
     partial accelerations into the receive buffer the kick kernel reads -- both enqueued by the library
-    on its own non-blocking stream with no host synchronisation.  RCCL refuses two ranks on one device,
+    with no host synchronisation.  overlap=1 (default): the all-gather runs on the communication stream
+    concurrently with the velocity half-kick, fenced by two events (re-sort steps take the serial form);
+    overlap=0: everything on the engine's stream.  RCCL refuses two ranks on one device,
     so the communicator has one rank; everything else (buffers, stream order, kernels) is the G > 1 path.
     The trajectory must equal the plain single-GPU one bit for bit."""
     monkeypatch.setenv("LJMD_N3_MIN_N", "1")
@@ -152,6 +155,7 @@ def test_rccl_collectives_really_issued_on_the_engine_stream(monkeypatch):
         sc_ref = ref.verlet_steps(25)                    # crosses a re-sort
         st_ref = ref.get_state()
     monkeypatch.setenv("LJMD_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("LJMD_OVERLAP_EXCHANGE", overlap)
     with Engine(p) as eng:
         eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         with pytest.raises(ljmd_amd.LjmdError, match="ljmd_comm_init"):
