@@ -322,14 +322,45 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
 }
 
 // 64 rotation steps of one column tile against the wave's 4 row tiles (see pair_n3_kernel).
+// The column POSITIONS are read-only, so they do not have to travel through DPP: the tile is parked in LDS
+// twice in a row (entries i and i + 64), and at step s lane l reads entry (l + 64 - s) -- the particle that a
+// rotation by s lanes would have brought to it -- with an immediate offset and no address arithmetic: three
+// ds_read_b64 on the LDS port, prefetched one step ahead, instead of six DPP moves on the VALU (LJMD_LDS_POS=0
+// at compile time restores the all-DPP form).  Only the partial accelerations still rotate.
+#ifndef LJMD_LDS_POS
+#define LJMD_LDS_POS 1
+#endif
+#ifndef LJMD_N3_UNROLL
+#define LJMD_N3_UNROLL 8
+#endif
+constexpr int kLdsAxis = 2 * kTile;         // doubles per axis in the parked column tile
+
 template <int NU, bool MASKED, bool INNER>
 __device__ __forceinline__ void column_tile_loop(const double (&xi)[kRowTiles], const double (&yi)[kRowTiles],
                                                  const double (&zi)[kRowTiles], double (&ax)[kRowTiles],
                                                  double (&ay)[kRowTiles], double (&az)[kRowTiles],
-                                                 double xj, double yj, double zj, unsigned mb,
+                                                 double xj, double yj, double zj, const double *park, unsigned mb,
                                                  double L, double invL, double rc2, double sx, double sy, double sz,
                                                  double &jx, double &jy, double &jz, double &s12, double &s6)
 {
+#if LJMD_LDS_POS
+    // park = &lds[lane]: entry (lane + 64 - s), s = 0 is the lane's own particle (already in xj, yj, zj)
+    double nx = xj, ny = yj, nz = zj;
+#pragma unroll LJMD_N3_UNROLL
+    for (int s = 0; s < kTile; ++s) {
+        xj = nx; yj = ny; zj = nz;
+        nx = park[kTile - 1 - s];                       // next step's particle; the last prefetch (entry lane) is unused
+        ny = park[kLdsAxis + kTile - 1 - s];
+        nz = park[2 * kLdsAxis + kTile - 1 - s];
+#pragma unroll
+        for (int k = 0; k < kRowTiles; ++k)
+            if (!MASKED || ((mb >> k) & 1u))
+                pair_n3<false, NU, INNER>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
+                                          ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+        jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
+    }
+#else
+    (void)park;
     for (int s = 0; s < kTile; ++s) {
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k)
@@ -339,6 +370,7 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[kRowTiles], 
         xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
         jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
     }
+#endif
 }
 
 // Wave-uniform image classification of one axis: raw differences xi - xj of all pairs lie in
@@ -356,6 +388,7 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
 {
     // ONE wave per workgroup: the waves are independent, and a 4-wave workgroup would hold its CU slots
     // until its slowest wave (different mask density per row group) has finished
+    __shared__ double parked[3 * kLdsAxis];                    // the current column tile, twice in a row per axis
     const int lane = threadIdx.x;
     const int Al = blockIdx.x;                                 // owned row group, wave-uniform
     const bool active = Al < a.NGo;
@@ -465,9 +498,20 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                     jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
                 }
             } else {
+#if LJMD_LDS_POS
+                // one wave per workgroup: the barriers only order this wave's own LDS traffic
+                __syncthreads();                               // the previous tile's reads are done
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double val = q == 0 ? xj : q == 1 ? yj : zj;
+                    parked[q * kLdsAxis + lane] = val;
+                    parked[q * kLdsAxis + kTile + lane] = val;
+                }
+                __syncthreads();
+#endif
 #define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
-    column_tile_loop<NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, mb, a.L, a.invL, a.rc2, sx, sy, \
-                                           sz, jx, jy, jz, s12, s6)
+    column_tile_loop<NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
+                                           a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
                 const bool all4 = mb == kAllRows;
                 if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
                 else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
