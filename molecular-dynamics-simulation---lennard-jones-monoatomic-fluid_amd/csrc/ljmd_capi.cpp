@@ -356,6 +356,33 @@ int refresh_perm(ljmd_t *h)
     return LJMD_OK;
 }
 
+// All collectives of the communicator go through ONE stream.  With the communication stream in use
+// (LJMD_OVERLAP_EXCHANGE=1, default) a collective is fenced against the engine's stream by two events:
+// comm_begin = "the engine's work so far is a prerequisite", comm_end = "the engine's later work waits for it".
+bool use_comm_stream(const ljmd_t *h) { return h->overlap_exchange && h->comm_stream != nullptr; }
+
+int comm_begin(ljmd_t *h)
+{
+    LJMD_HIP(h, hipEventRecord(h->ev_pos_ready, h->stream));
+    LJMD_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_pos_ready, 0));
+    return LJMD_OK;
+}
+
+int comm_end(ljmd_t *h)
+{
+    LJMD_HIP(h, hipEventRecord(h->ev_gather_done, h->comm_stream));
+    LJMD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gather_done, 0));
+    return LJMD_OK;
+}
+
+int allgather_on(ljmd_t *h, hipStream_t s)
+{
+    // in place: the send block is this rank's slice of the receive buffer
+    const ncclResult_t r = ncclAllGather(own_block(h), h->d_pos, 3 * (size_t)h->P, ncclDouble, h->comm, s);
+    if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
+    return LJMD_OK;
+}
+
 // Phase A: pair kernel on the exchange buffer + deterministic slab reduction into fpart.
 int enqueue_pair_forces(ljmd_t *h, EventSet *q)
 {
@@ -418,9 +445,18 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
 {
     if (needs_force_exchange(h) && !h->external_force_exchange) {
         if (!h->comm) return fail(h, LJMD_ERR_STATE, "multi-rank Newton-3 step: call ljmd_comm_init first");
+        const bool cs = use_comm_stream(h);
+        if (cs) {
+            const int rc_ = comm_begin(h);
+            if (rc_ != LJMD_OK) return rc_;
+        }
         const ncclResult_t r = ncclReduceScatter(h->d_fpart, h->d_frecv, 3 * (size_t)h->P, ncclDouble, ncclSum,
-                                                 h->comm, h->stream);
+                                                 h->comm, cs ? h->comm_stream : h->stream);
         if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclReduceScatter failed: %s", ncclGetErrorString(r));
+        if (cs) {
+            const int rc_ = comm_end(h);
+            if (rc_ != LJMD_OK) return rc_;
+        }
     }
     LJMD_HIP(h, launch_kick(integrate_args(h), kick, h->stream));
     LJMD_HIP(h, launch_finalize(finalize_args(h, h->pending_n_wg, kick, h->pending_scale), h->d_fold, h->stream));
@@ -437,31 +473,22 @@ int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
     return rc_ != LJMD_OK ? rc_ : enqueue_kick(h, kick, q);
 }
 
-int allgather_on(ljmd_t *h, hipStream_t s)
-{
-    // in place: the send block is this rank's slice of the receive buffer
-    const ncclResult_t r = ncclAllGather(own_block(h), h->d_pos, 3 * (size_t)h->P, ncclDouble, h->comm, s);
-    if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(r));
-    return LJMD_OK;
-}
-
 int enqueue_drift(ljmd_t *h, EventSet *q)
 {
     if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
     h->gather_done_for_step = false;
     const bool resort_now = h->sort_enabled && fast_path_ok(h) && h->steps_since_sort + 1 >= h->resort_every;
     const bool collectives = h->comm && (h->G > 1 || h->force_collectives);
-    if (collectives && h->overlap_exchange && !resort_now) {
+    if (collectives && use_comm_stream(h) && !resort_now) {
         // positions first; the all-gather starts on the communication stream as soon as they are final and
         // overlaps the velocity half-kick; the engine's stream resumes (geometry pre-pass, pair kernel) when
         // the gathered positions have arrived.  (Re-sort steps permute the block after K1: serial path below.)
         LJMD_HIP(h, launch_drift_kick(integrate_args(h), 1, h->stream));
-        LJMD_HIP(h, hipEventRecord(h->ev_pos_ready, h->stream));
-        LJMD_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_pos_ready, 0));
-        const int rc_ = allgather_on(h, h->comm_stream);
+        int rc_ = comm_begin(h);
+        if (rc_ == LJMD_OK) rc_ = allgather_on(h, h->comm_stream);
         if (rc_ != LJMD_OK) return rc_;
         LJMD_HIP(h, hipEventRecord(h->ev_gather_done, h->comm_stream));
-        LJMD_HIP(h, launch_drift_kick(integrate_args(h), 2, h->stream));
+        LJMD_HIP(h, launch_drift_kick(integrate_args(h), 2, h->stream));     // runs while the gather is in flight
         LJMD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gather_done, 0));
         h->gather_done_for_step = true;
     } else {
@@ -1223,9 +1250,13 @@ int ljmd_allgather_positions(ljmd_t *h)
         h->gather_done_for_step = false;
         return LJMD_OK;
     }
-    // serial form (t = 0, re-sort steps, LJMD_OVERLAP_EXCHANGE=0): on the engine's stream, i.e. behind the
-    // drift/kick (and re-sort) kernels and ahead of the pair kernel
-    return allgather_on(h, h->stream);
+    // serial form (t = 0, re-sort steps, LJMD_OVERLAP_EXCHANGE=0): behind the drift/kick (and re-sort) kernels
+    // and ahead of the pair kernel
+    if (!use_comm_stream(h)) return allgather_on(h, h->stream);
+    int rc_ = comm_begin(h);
+    if (rc_ == LJMD_OK) rc_ = allgather_on(h, h->comm_stream);
+    if (rc_ == LJMD_OK) rc_ = comm_end(h);
+    return rc_;
 }
 
 int ljmd_memcpy(ljmd_t *h, void *dst, const void *src, int64_t bytes, int32_t kind)
