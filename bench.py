@@ -110,6 +110,8 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
+    # dmabuf IPC: the only mode the host driver of this pool supports for cross-process device memory (RCCL)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     # HIP runtime bookkeeping: torch ships its own libamdhip64 / librccl / libhsa-runtime64 (same SONAMEs as
     # the system ROCm ones).  torch is imported FIRST here, so when libljmd.so is loaded next the dynamic
