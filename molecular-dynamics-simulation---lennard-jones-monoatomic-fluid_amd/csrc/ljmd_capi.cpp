@@ -29,6 +29,9 @@ thread_local std::string g_last_error = "";
 
 constexpr unsigned kRingCap = 4096;     // per-step partial records kept on the device
 constexpr int kTargetWorkgroups = 2048; // >> 256 CUs (8 per CU) for the pair kernels
+constexpr int kMixedMinN = 16384;       // smallest system the mixed-precision mode accepts
+constexpr long kN3ItemsFor4 = 40000;    // Newton-3 work items (row groups x offsets) a rank needs before 4 ...
+constexpr long kN3ItemsFor2 = 6144;     // ... or 2 tiles per row group pay off
 constexpr int kMaxProfiledLaunches = 4096;
 constexpr int kEventsPerLaunch = 5;
 
@@ -103,6 +106,7 @@ struct ljmd {
     bool use_n3 = false;
     int n3_waves = 3;                 // LJMD_N3_WAVES: register-budget variant of the Newton-3 kernel
     int NG = 0, NGo = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
+    int rt = kRowTiles;               // tiles per row group (LJMD_N3_ROW_TILES; auto: 4, or 2 / 1 for small systems)
     double *d_slab_j = nullptr;
     unsigned char *d_flag_j = nullptr;
     // mixed precision (mode = LJMD_PRECISION_FP32_FORCE): far tile pairs in fp32
@@ -198,6 +202,7 @@ GeometryArgs geometry_args(ljmd_t *h)
     a.TB = h->TB;
     a.T = h->T;
     a.W = h->W;
+    a.RT = h->rt;
     a.L = h->L;
     a.rc2_skin = h->rc2 * (1.0 + 1e-10);
     a.mask_far = h->d_mask_far;       // NULL unless mixed precision
@@ -227,6 +232,7 @@ N3Args n3_args(ljmd_t *h)
     a.Dmax = h->Dmax;
     a.Q = h->Q;
     a.dchunk = h->dchunk;
+    a.RT = h->rt;
     a.L = h->L;
     a.invL = h->invL;
     a.rc2 = h->rc2;
@@ -272,6 +278,7 @@ ReduceArgs reduce_args(ljmd_t *h, int nslab, bool n3)
     a.NGo = h->NGo;
     a.Dmax = h->Dmax;
     a.Q = h->Q;
+    a.RT = h->rt;
     return a;
 }
 
@@ -714,11 +721,23 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->nslab_t = (h->T + h->chunk_t - 1) / h->chunk_t;
     }
     {   // Newton-3 kernel: NG row groups over all ranks, NGo owned; offsets 0..Dmax in slices
-        h->NGo = h->TB / kRowTiles;
+        // tiles per row group: 4 is the measured optimum when there is plenty of work; small systems take 2 or
+        // 1 so that (row groups) x (offsets) still fills the 1024 SIMDs
+        const bool mixed_mode = precision_mode == LJMD_PRECISION_FP32_FORCE;
+        int rt = env_int("LJMD_N3_ROW_TILES", 0);
+        if (mixed_mode) rt = kRowTiles;                       // the fp32 far kernel is built for 4
+        if (rt != 1 && rt != 2 && rt != kRowTiles) {
+            // measured (tools/sweep_small_n.sh, profiles/r01_sweep_pair_variants.txt): 4 wins from n = 131072 up,
+            // 2 for 16384..65536, 1 below
+            auto items = [&](int cand) { const long ngo = h->TB / cand; return ngo * ((long)h->G * ngo / 2 + 1); };
+            rt = items(kRowTiles) >= kN3ItemsFor4 ? kRowTiles : items(2) >= kN3ItemsFor2 ? 2 : 1;
+        }
+        h->rt = rt;
+        h->NGo = h->TB / rt;
         h->NG = h->G * h->NGo;
         h->Dmax = h->NG / 2;
-        h->Q = (h->Dmax + 1) * kRowTiles;
-        const int n3_min = env_int("LJMD_N3_MIN_N", 16384);
+        h->Q = (h->Dmax + 1) * rt;
+        const int n3_min = env_int("LJMD_N3_MIN_N", 4096);
         h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min;
         h->n3_waves = env_int("LJMD_N3_WAVES", 3);
         const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 65536));
@@ -728,11 +747,11 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->nslab_n = (h->Dmax + 1 + h->dchunk - 1) / h->dchunk;
     }
     const bool mixed = precision_mode == LJMD_PRECISION_FP32_FORCE;
-    if (mixed && !h->use_n3) {
+    if (mixed && (!h->use_n3 || n < kMixedMinN)) {
+        // the fp32 far kernel works on 4-tile row groups and only pays where most pairs are far pairs
         delete h;
         return fail(nullptr, LJMD_ERR_INVALID_ARG,
-                    "ljmd_create: LJMD_PRECISION_FP32_FORCE needs the Newton-3 path (n >= %d)",
-                    env_int("LJMD_N3_MIN_N", 16384));
+                    "ljmd_create: LJMD_PRECISION_FP32_FORCE needs the Newton-3 path and n >= %d", kMixedMinN);
     }
     {
         const char *rs = std::getenv("LJMD_FP32_SPLIT");

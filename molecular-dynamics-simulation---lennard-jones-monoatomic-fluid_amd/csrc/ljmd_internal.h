@@ -58,7 +58,8 @@ struct N3Args {
     unsigned char *flag_j;  // [NGo][Q] 1 = slab_j block written this step
     double *wg_part;        // [n workgroups][2]
     int S, P, G, rank, TB, T, W;   // S = real particles per rank (slots S..P-1 are padding)
-    int NG, NGo, Dmax, Q;   // row groups in total / owned by this rank (NGo = TB / 4, NG = G * NGo)
+    int NG, NGo, Dmax, Q;   // row groups in total / owned by this rank (NGo = TB / RT, NG = G * NGo), Q = (Dmax+1)*RT
+    int RT;                 // tiles per row group: 4 for large systems, 1 or 2 to give small ones enough work items
     int dchunk;             // offsets d per grid.y slice
     double L, invL, rc2;
 };
@@ -86,6 +87,7 @@ struct ReduceArgs {
     const unsigned char *flag_j2;
     double *fpart;
     int nslab, P, G, rank, TB, NG, NGo, Dmax, Q;
+    int RT;                 // tiles per Newton-3 row group of this engine (1, 2 or 4)
 };
 
 struct FinalizeArgs {
@@ -105,6 +107,7 @@ struct GeometryArgs {
     uint64_t *mask_far;     // mixed precision only (else NULL): [TB][W] tile pairs evaluated in fp32;
                             // `mask` then holds only the NEAR pairs (box distance <= r_split, or same row group)
     int P, G, rank, TB, T, W;
+    int RT;                 // tiles per Newton-3 row group (same-group pairs always count as NEAR)
     double L, rc2_skin;     // rc^2 * (1 + 1e-10): skip only when provably outside
     double rsplit2;         // r_split^2
 };
@@ -126,7 +129,7 @@ struct SortArgs {
 
 hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s);
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s);   // dispatches on a.RT
 hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, int phase /* 0 all, 1 positions, 2 velocities */, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);

@@ -335,10 +335,10 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
 #endif
 constexpr int kLdsAxis = 2 * kTile;         // doubles per axis in the parked column tile
 
-template <int NU, bool MASKED, bool INNER>
-__device__ __forceinline__ void column_tile_loop(const double (&xi)[kRowTiles], const double (&yi)[kRowTiles],
-                                                 const double (&zi)[kRowTiles], double (&ax)[kRowTiles],
-                                                 double (&ay)[kRowTiles], double (&az)[kRowTiles],
+template <int RT, int NU, bool MASKED, bool INNER>
+__device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const double (&yi)[RT],
+                                                 const double (&zi)[RT], double (&ax)[RT],
+                                                 double (&ay)[RT], double (&az)[RT],
                                                  double xj, double yj, double zj, const double *park, unsigned mb,
                                                  double L, double invL, double rc2, double sx, double sy, double sz,
                                                  double &jx, double &jy, double &jz, double &s12, double &s6)
@@ -353,7 +353,7 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[kRowTiles], 
         ny = park[kLdsAxis + kTile - 1 - s];
         nz = park[2 * kLdsAxis + kTile - 1 - s];
 #pragma unroll
-        for (int k = 0; k < kRowTiles; ++k)
+        for (int k = 0; k < RT; ++k)
             if (!MASKED || ((mb >> k) & 1u))
                 pair_n3<false, NU, INNER>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
                                           ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
@@ -363,7 +363,7 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[kRowTiles], 
     (void)park;
     for (int s = 0; s < kTile; ++s) {
 #pragma unroll
-        for (int k = 0; k < kRowTiles; ++k)
+        for (int k = 0; k < RT; ++k)
             if (!MASKED || ((mb >> k) & 1u))
                 pair_n3<false, NU, INNER>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
                                           ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
@@ -383,7 +383,7 @@ __device__ __forceinline__ bool uniform_image(double lo, double hi, double L, do
     return (tlo > n - 0.5 + 1e-9) && (thi < n + 0.5 - 1e-9) && (fabs(n) <= 2.0);
 }
 
-template <int MIN_WAVES>
+template <int MIN_WAVES, int RT>
 __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
 {
     // ONE wave per workgroup: the waves are independent, and a 4-wave workgroup would hold its CU slots
@@ -396,12 +396,12 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
     const size_t P = a.P;
     const double *own = a.pos + (size_t)a.rank * 3 * P;
 
-    double xi[kRowTiles], yi[kRowTiles], zi[kRowTiles];
-    double ax[kRowTiles], ay[kRowTiles], az[kRowTiles];
+    double xi[RT], yi[RT], zi[RT];
+    double ax[RT], ay[RT], az[RT];
     double s12 = 0.0, s6 = 0.0;
 #pragma unroll
-    for (int k = 0; k < kRowTiles; ++k) {
-        const size_t slot = (size_t)(active ? kRowTiles * Al + k : 0) * kTile + lane;
+    for (int k = 0; k < RT; ++k) {
+        const size_t slot = (size_t)(active ? RT * Al + k : 0) * kTile + lane;
         xi[k] = own[slot];
         yi[k] = own[P + slot];
         zi[k] = own[2 * P + slot];
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
     {
         double mx[3] = {xi[0], yi[0], zi[0]}, Mx[3] = {xi[0], yi[0], zi[0]};
 #pragma unroll
-        for (int k = 1; k < kRowTiles; ++k) {
+        for (int k = 1; k < RT; ++k) {
             mx[0] = fmin(mx[0], xi[k]); mx[1] = fmin(mx[1], yi[k]); mx[2] = fmin(mx[2], zi[k]);
             Mx[0] = fmax(Mx[0], xi[k]); Mx[1] = fmax(Mx[1], yi[k]); Mx[2] = fmax(Mx[2], zi[k]);
         }
@@ -424,21 +424,21 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
         }
     }
 
-    const bool group_full = (kRowTiles * Al + kRowTiles) * kTile <= a.S;   // no padding slot among the 256 rows
+    const bool group_full = (RT * Al + RT) * kTile <= a.S;   // no padding slot among the 256 rows
     const int d0 = blockIdx.y * a.dchunk;
     const int d1 = active ? min(d0 + a.dchunk, a.Dmax + 1) : d0;
     for (int d = d0; d < d1; ++d) {
         int B = A + d;
         if (B >= a.NG) B -= a.NG;
         const bool own = (d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B);
-        for (int l = 0; l < kRowTiles; ++l) {
-            const int c = kRowTiles * B + l;                   // column tile (global)
-            const size_t blk = (size_t)Al * a.Q + (size_t)d * kRowTiles + l;
+        for (int l = 0; l < RT; ++l) {
+            const int c = RT * B + l;                   // column tile (global)
+            const size_t blk = (size_t)Al * a.Q + (size_t)d * RT + l;
             unsigned mb = 0;
             if (own) {
 #pragma unroll
-                for (int k = 0; k < kRowTiles; ++k) {
-                    const uint64_t w = a.mask[(size_t)(kRowTiles * Al + k) * a.W + (c >> 6)];
+                for (int k = 0; k < RT; ++k) {
+                    const uint64_t w = a.mask[(size_t)(RT * Al + k) * a.W + (c >> 6)];
                     mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
                 }
                 if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 // the column tile is one of the wave's own row tiles: tile l against itself
                 for (int s = 0; s < kTile; ++s) {
 #pragma unroll
-                    for (int k = 0; k < kRowTiles; ++k) {
+                    for (int k = 0; k < RT; ++k) {
                         if (!((mb >> k) & 1u)) continue;
                         if (k == l) {
                             if (s >= 1 && s <= 32)
@@ -510,9 +510,9 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 __syncthreads();
 #endif
 #define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
-    column_tile_loop<NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
+    column_tile_loop<RT, NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
                                            a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
-                const bool all4 = mb == kAllRows;
+                const bool all4 = mb == ((1u << RT) - 1u);
                 if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
                 else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
                 else if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
@@ -534,8 +534,8 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
     if (active) {
         double *si = a.slab_i + (size_t)blockIdx.y * 3 * P;
 #pragma unroll
-        for (int k = 0; k < kRowTiles; ++k) {
-            const size_t slot = (size_t)(kRowTiles * Al + k) * kTile + lane;
+        for (int k = 0; k < RT; ++k) {
+            const size_t slot = (size_t)(RT * Al + k) * kTile + lane;
             si[slot] = ax[k];
             si[P + slot] = ay[k];
             si[2 * P + slot] = az[k];
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
         keep = !(d2 > a.rc2_skin) || (J == I);
         if (a.mask_far) {
             // mixed precision: fp64 for boxes closer than r_split and inside the own row group, fp32 beyond
-            const bool near = (d2 <= a.rsplit2) || (J / kRowTiles == I / kRowTiles);
+            const bool near = (d2 <= a.rsplit2) || (J / a.RT == I / a.RT);
             far = keep && !near;
             keep = keep && near;
         }
@@ -869,13 +869,13 @@ __global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
     }
     if constexpr (N3) {
         const int c = g * a.TB + blockIdx.x;                    // global column tile (= this workgroup's tile)
-        const int B = c / kRowTiles, l = c - B * kRowTiles;
+        const int B = c / a.RT, l = c - B * a.RT;
         const int A0 = a.rank * a.NGo;
         for (int Al = q; Al < a.NGo; Al += kWavesPerBlock) {
             int d = B - (A0 + Al);
             if (d < 0) d += a.NG;
             if (d > a.Dmax) continue;
-            const size_t blk = (size_t)Al * a.Q + (size_t)d * kRowTiles + l;
+            const size_t blk = (size_t)Al * a.Q + (size_t)d * a.RT + l;
             if (a.flag_j[blk]) {
                 const double *b = a.slab_j + blk * (3 * kTile) + lane;
                 s[0] += b[0];
@@ -1071,12 +1071,16 @@ hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s)
 hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s)
 {
     // register budget variants (occupancy vs spills); the default is chosen by measurement
-    if (min_waves <= 3)
-        hipLaunchKernelGGL(pair_n3_kernel<3>, grid, dim3(kTile), 0, s, a);
+    if (a.RT == 1)
+        hipLaunchKernelGGL((pair_n3_kernel<3, 1>), grid, dim3(kTile), 0, s, a);
+    else if (a.RT == 2)
+        hipLaunchKernelGGL((pair_n3_kernel<3, 2>), grid, dim3(kTile), 0, s, a);
+    else if (min_waves <= 3)
+        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles>), grid, dim3(kTile), 0, s, a);
     else if (min_waves == 4)
-        hipLaunchKernelGGL(pair_n3_kernel<4>, grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<4, kRowTiles>), grid, dim3(kTile), 0, s, a);
     else
-        hipLaunchKernelGGL(pair_n3_kernel<5>, grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<5, kRowTiles>), grid, dim3(kTile), 0, s, a);
     return hipGetLastError();
 }
 

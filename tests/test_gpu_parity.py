@@ -38,7 +38,9 @@ def check_force(scalars, a, g):
 
 
 @pytest.mark.parametrize("name", ["force_n108", "force_n500", "force_n4000", "force_n4096"])
-def test_force_call_vs_reference_golden(golden, name):
+def test_force_call_vs_reference_golden(golden, name, monkeypatch):
+    """The gather (full ordered matrix) tile kernel, which serves systems below 4096 particles."""
+    monkeypatch.setenv("LJMD_N3", "0")
     g = golden(name)
     n = int(g["n"])
     p = init_params(n, float(g["L"]), 0.005, float(g["rc"]))
@@ -50,12 +52,15 @@ def test_force_call_vs_reference_golden(golden, name):
     check_force(sc, a, g)
 
 
+@pytest.mark.parametrize("row_tiles", ["1", "2", "4"])
 @pytest.mark.parametrize("name", ["force_n108", "force_n500", "force_n4000", "force_n4096"])
-def test_newton3_kernel_vs_reference_golden(golden, name, monkeypatch):
-    """The Newton-3 rotation kernel normally engages at N >= 16384; force it at the golden sizes.
+def test_newton3_kernel_vs_reference_golden(golden, name, row_tiles, monkeypatch):
+    """The Newton-3 rotation kernel normally engages at N >= 4096 (1 tile per row group there, 2 from 16384,
+    4 from 131072); force it at the golden sizes in all three instantiations.  With 4 tiles per group:
     N=108 -> one row group (diagonal only), N=500 -> two groups (the d = NG/2 tie rule),
     N=4000/4096 -> 16 groups, 9 offsets."""
     monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+    monkeypatch.setenv("LJMD_N3_ROW_TILES", row_tiles)
     g = golden(name)
     n = int(g["n"])
     p = init_params(n, float(g["L"]), 0.005, float(g["rc"]))
