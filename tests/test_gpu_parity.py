@@ -344,6 +344,46 @@ def test_large_n_properties_262144():
         assert np.abs(a_np - a1[:, i]).max() < 1e-10 * max(np.abs(a_np).max(), 1.0)
 
 
+def test_bench_configuration_full_parity_vs_oracle_n262144(oracle):
+    """The EXACT bench workload (BASELINE config 3: n = 262144, production kernel configuration), one force
+    evaluation, against the CPU oracle over ALL 6.9e10 ordered pairs (OpenMP full-matrix form of the oracle:
+    the reference's per-pair arithmetic, rows independent) -- every acceleration and the three scalars.
+    ~40 s of host time on the GPU box's 16-core CPU share."""
+    import ctypes
+    import os
+    n = 262144
+    p, r, v = synthetic.make_config(n)
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e, d, dd = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    po = oracle.derive_params(p.n, p.box_length, p.dt, p.rc)
+    x, y, z = (np.ascontiguousarray(q) for q in r)
+    ao = np.empty((3, n))
+    se = sd = sdd = 0.0
+    for i0 in range(0, n, 32768):
+        ax, ay, az, pe, pd, pdd = oracle.rows_raw(po, i0, i0 + 32768, x, y, z)
+        ao[0, i0:i0 + 32768], ao[1, i0:i0 + 32768], ao[2, i0:i0 + 32768] = ax, ay, az
+        se, sd, sdd = se + pe, sd + pd, sdd + pdd
+    te, td, tdd = oracle.tail_corrections(po)
+    ref = (4.0 * (0.5 * se) + te, 24.0 * (0.5 * sd) + td, 24.0 * (0.5 * sdd) + tdd)   # every unordered pair seen twice
+    for name, mine, want in zip(("epot", "d_epot", "dd_epot"), (e, d, dd), ref):
+        assert rel(mine, want) <= 1e-12, (name, mine, want, rel(mine, want))
+    ao *= 24.0
+    assert np.abs(a - ao).max() <= REL_ACCEL * np.abs(ao).max(), np.abs(a - ao).max() / np.abs(ao).max()
+
+
 def test_fast_path_equals_generic_path(golden, monkeypatch):
     """The sorted / tile-skipping / rcp+Newton fast path against the exact generic kernel
     (dnint minimum image, IEEE divide, no sorting, no skipping) on the same device."""
