@@ -25,7 +25,7 @@ REF = ROOT / "oracle" / "_ref"
 
 
 def _workdir(tmp_path, tag):
-    src = GOLDEN / f"ref_run_n108_{tag}"
+    src = GOLDEN / (tag if tag.startswith("ref_run_") else f"ref_run_n108_{tag}")
     (tmp_path / "inputs").mkdir()
     (tmp_path / "outputs" / "one_run").mkdir(parents=True)
     shutil.copy(src / "input_simulation_parameters.txt", tmp_path / "inputs")
@@ -137,6 +137,25 @@ def test_thin_fortran_pipeline_init_then_production(tmp_path):
     assert np.abs(r1 - r2).max() < 1e-10 and np.abs(v1 - v2).max() < 1e-9
     subprocess.run([str(PKG / "bin" / "md_simulation_gpu")], cwd=tmp_path, check=True, timeout=120)
     _compare_run(tmp_path, src, 9)
+
+
+def test_thin_fortran_pipeline_second_configuration(tmp_path):
+    """Everything different from config 1: k = 4 (N = 256), L = 6.5 (rho = 0.93), rc = 0.35 L, dt = 0.002,
+    target energy -900, 600 steps sampled every 20 after 40.  Our init driver + our production driver against
+    the files the reference's two programs wrote for this input."""
+    src = _workdir(tmp_path, "ref_run_n256_k4")
+    (tmp_path / "outputs" / "rv_init.dat").unlink()
+    subprocess.run([str(PKG / "bin" / "md_initial_config_gpu")], cwd=tmp_path, check=True, timeout=120)
+    r1, v1 = io_formats.read_rv_init(tmp_path / "outputs" / "rv_init.dat", 256)
+    r2, v2 = io_formats.read_rv_init(src / "rv_init.dat", 256)
+    assert (tmp_path / "outputs" / "rv_init.dat").stat().st_size == 2 * (3 * 256 * 8 + 8)
+    assert np.abs(r1 - r2).max() < 1e-10 and np.abs(v1 - v2).max() < 1e-9
+    subprocess.run([str(PKG / "bin" / "md_simulation_gpu")], cwd=tmp_path, check=True, timeout=120)
+    _compare_run(tmp_path, src, 28)
+    _compare_statistics_files(tmp_path / "outputs" / "one_run", src)
+    h, snaps = io_formats.read_rva(tmp_path / "outputs" / "one_run" / "rva.dat")
+    assert h == dict(n=256, box_length=6.5, dt=0.002, output_interval=20, n_snapshots_expected=28)
+    assert snaps.shape == (28, 4, 3, 256)
 
 
 @pytest.mark.skipif(not (REF / "md_simulation_program_gpu").exists(),

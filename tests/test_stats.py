@@ -21,17 +21,26 @@ REPLAY = PKG / "bin" / "md_stats_replay"
 FILES = [f"{kind}_{obs}.dat" for kind in ("corr", "corrmean") for obs in stats.OBSERVABLES] + ["md_final_results.txt"]
 
 
-def _samples(oi):
-    sc = np.load(GOLDEN / "traj_n108.npz")["scalars"]            # [10001, 4]: epot, ekin, d_epot, dd_epot after k steps
-    return sc[100 + oi:1001:oi]                                   # sampling condition: step > 100 and step % oi == 0
+# (fixture directory, raw scalars, output_interval, warmup_steps, total_steps, samples)
+CASES = {"oi10": ("ref_run_n108_oi10", "traj_n108.npz", 10, 100, 1000, 90),
+         "oi100": ("ref_run_n108_oi100", "traj_n108.npz", 100, 100, 1000, 9),
+         # k = 4 (N = 256), rc = 0.35 L, dt = 0.002, L = 6.5, sampling every 20 after 40: differs from config 1 everywhere
+         "k4": ("ref_run_n256_k4", "traj_n256_k4.npz", 20, 40, 600, 28)}
 
 
-@pytest.mark.parametrize("oi,n_samples", [(10, 90), (100, 9)])
-def test_python_mirror_reproduces_reference_files(tmp_path, oi, n_samples):
-    src = GOLDEN / f"ref_run_n108_oi{oi}"
+def _samples(case):
+    _d, traj, oi, warm, total, _n = CASES[case]
+    sc = np.load(GOLDEN / traj)["scalars"]                       # [steps + 1, 4]: epot, ekin, d_epot, dd_epot after k steps
+    first = (warm // oi + 1) * oi                                # sampling condition: step > warmup and step % oi == 0
+    return sc[first:total + 1:oi]
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_python_mirror_reproduces_reference_files(tmp_path, case):
+    src = GOLDEN / CASES[case][0]
     ctl = read_simulation_parameters(src / "input_simulation_parameters.txt")
-    s = _samples(oi)
-    assert s.shape == (n_samples, 4)
+    s = _samples(case)
+    assert s.shape == (CASES[case][5], 4)
     acc = stats.RunStatistics(ctl.params.n, ctl.params.volume)
     energies = [ln.split() for ln in (src / "instantaneous_energies.dat").read_text().splitlines()[1:]]
     for row, ref_row in zip(s, energies):
@@ -42,20 +51,20 @@ def test_python_mirror_reproduces_reference_files(tmp_path, oi, n_samples):
     out = stats.write_run_statistics(tmp_path, ctl.params, ctl.total_steps, ctl.output_interval, ctl.warmup_steps, acc)
     for name in FILES:
         assert (tmp_path / name).read_text() == (src / name).read_text(), name
-    if oi == 10:
+    if case == "oi10":
         assert abs(out["coefficients"]["gamma"] - 2.848590910736) < 1e-11
 
 
 @pytest.mark.skipif(not REPLAY.exists(), reason="run __graft_entry__.build() first (needs amdflang)")
-@pytest.mark.parametrize("oi", [10, 100])
-def test_fortran_statistics_modules_reproduce_reference_files(tmp_path, oi):
+@pytest.mark.parametrize("case", list(CASES))
+def test_fortran_statistics_modules_reproduce_reference_files(tmp_path, case):
     """fortran/md_stats.f90 + md_run_outputs.f90 (what md_simulation_gpu links), driven by the
     CPU-only replay tool."""
-    src = GOLDEN / f"ref_run_n108_oi{oi}"
+    src = GOLDEN / CASES[case][0]
     (tmp_path / "inputs").mkdir()
     (tmp_path / "outputs" / "one_run").mkdir(parents=True)
     shutil.copy(src / "input_simulation_parameters.txt", tmp_path / "inputs")
-    _samples(oi).astype("<f8").tofile(tmp_path / "outputs" / "one_run" / "samples.bin")
+    _samples(case).astype("<f8").tofile(tmp_path / "outputs" / "one_run" / "samples.bin")
     subprocess.run([str(REPLAY)], cwd=tmp_path, check=True, timeout=60)
     for name in FILES:
         assert (tmp_path / "outputs" / "one_run" / name).read_bytes() == (src / name).read_bytes(), name
