@@ -740,7 +740,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         const int n3_min = env_int("LJMD_N3_MIN_N", 4096);
         h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min;
         h->n3_waves = env_int("LJMD_N3_WAVES", 3);
-        const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 65536));
+        const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 131072));
         int ns = (target_waves + h->NGo - 1) / h->NGo;
         ns = std::max(1, std::min(ns, h->Dmax + 1));
         h->dchunk = (h->Dmax + 1 + ns - 1) / ns;
