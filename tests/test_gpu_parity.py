@@ -635,3 +635,37 @@ def test_resume_from_an_rva_snapshot(golden, tmp_path):
         assert np.max(np.abs(x - y) / np.abs(x)) < 1e-11
     for key in ("r", "ru", "v"):
         assert np.abs(np.stack(fin_a[key]) - np.stack(fin_b[key])).max() < 1e-10, key
+
+
+def test_config2_10000_steps_vs_the_references_own_series():
+    """BASELINE config 2 (N = 4096, 10 000 steps) against the raw per-step scalars of the REAL reference run to
+    the same length from the same start (tests/golden/traj_n4096_10000.npz, 41 min of one core, produced by
+    oracle/ref_harness over the reference's modules).  Inside the chaos horizon: step by step, 1e-10.  Beyond it
+    the two trajectories are different members of the same NVE ensemble: equal conserved energy (block means),
+    equal <T> and <P> within their statistical error."""
+    from ljmd_amd.physics import observables
+    g = np.load(GOLDEN / "traj_n4096_10000.npz")
+    ref = g["scalars"]                                          # [10001, 4] incl. t = 0
+    n = 4096
+    p, r, v = synthetic.make_config(n)
+    assert float(g["L"]) == p.box_length and float(g["rc"]) == p.rc
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e0, d0, dd0 = eng.compute_forces()
+        k0 = eng.kinetic_energy()
+        e, k, d, dd = eng.verlet_steps(10000)
+    mine = np.vstack([[e0, k0, d0, dd0], np.stack([e, k, d, dd], axis=1)])
+    et, er = mine[:, 0] + mine[:, 1], ref[:, 0] + ref[:, 1]
+    rel = np.abs(et - er) / np.abs(er)
+    assert rel[:201].max() <= REL_TRAJ                           # 200 steps: 1e-10
+    horizon = int(np.argmax(rel > REL_TRAJ))
+    assert horizon > 300, horizon                                # the reference leaves ITSELF (FMA on/off) at ~950 for N = 108
+    # conserved quantity: means over the second half agree far inside the instantaneous fluctuation
+    fluct = er[5000:].std() / abs(er.mean())
+    assert abs(et[5000:].mean() - er[5000:].mean()) / abs(er.mean()) < 0.5 * fluct
+    assert abs(et[5000:].std() / er[5000:].std() - 1.0) < 0.25   # same fluctuation level
+    Tm, Tr = 2.0 * mine[5000:, 1].mean() / (3.0 * n), 2.0 * ref[5000:, 1].mean() / (3.0 * n)
+    assert abs(Tm / Tr - 1.0) < 5e-3
+    Pm = np.mean([observables(p, a, b, c)[2] for a, b, c in mine[5000:, :3]])
+    Pr = np.mean([observables(p, a, b, c)[2] for a, b, c in ref[5000:, :3]])
+    assert abs(Pm / Pr - 1.0) < 2e-2
