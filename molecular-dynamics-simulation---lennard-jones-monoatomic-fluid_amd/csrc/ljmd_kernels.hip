@@ -295,12 +295,17 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
                                         double &jx, double &jy, double &jz,
                                         double &s12, double &s6)
 {
-    // NU: bit k set = axis k needs the general minimum image (4 instructions); clear = the image is the
+    // NU < 8: bit k set = axis k needs the general minimum image (4 instructions); clear = the image is the
     // same for the whole (row group, column tile) and the shift is subtracted (2 instructions)
     // NU == 8: the common image is n = 0 on all three axes: d = xi - xj (1 instruction per axis)
-    const double dx = (NU == 8) ? (xi - xj) : (NU & 1) ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
-    const double dy = (NU == 8) ? (yi - yj) : (NU & 2) ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
-    const double dz = (NU == 8) ? (zi - zj) : (NU & 4) ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
+    // NU == 16 + a: every axis has a common image and only axis a's is non-zero: one subtraction more on that
+    // axis, none on the others ((d - 0.0) == d, so this is the NU == 0 result bit for bit)
+    constexpr bool gx = NU < 8 && (NU & 1), gy = NU < 8 && (NU & 2), gz = NU < 8 && (NU & 4);
+    constexpr bool px = NU == 8 || (NU >= 16 && NU != 16), py = NU == 8 || (NU >= 16 && NU != 17),
+                   pz = NU == 8 || (NU >= 16 && NU != 18);
+    const double dx = px ? (xi - xj) : gx ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
+    const double dy = py ? (yi - yj) : gy ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
+    const double dz = pz ? (zi - zj) : gz ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
     const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
     bool in = true;
     if constexpr (!INNER) in = r2 < rc2;       // INNER: the boxes prove r^2 < rc^2 for every pair
@@ -475,7 +480,10 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 if (nu & 2) sy = 0.0;
                 if (nu & 4) sz = 0.0;
                 if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
-                if (nu == 0 && sx == 0.0 && sy == 0.0 && sz == 0.0) nu = 8;   // no periodic image at all
+                if (nu == 0) {
+                    const int nz = __builtin_amdgcn_readfirstlane((sx != 0.0 ? 1 : 0) | (sy != 0.0 ? 2 : 0) | (sz != 0.0 ? 4 : 0));
+                    nu = nz == 0 ? 8 : nz == 1 ? 16 : nz == 2 ? 17 : nz == 4 ? 18 : 0;   // none / one axis / several
+                }
             }
 
             if (d == 0 && ((mb >> l) & 1u)) {
@@ -515,6 +523,12 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 const bool all4 = mb == ((1u << RT) - 1u);
                 if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
                 else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
+                else if (nu == 16 && inner) { if (all4) LJMD_LOOP(16, false, true); else LJMD_LOOP(16, true, true); }
+                else if (nu == 16)    { if (all4) LJMD_LOOP(16, false, false); else LJMD_LOOP(16, true, false); }
+                else if (nu == 17 && inner) { if (all4) LJMD_LOOP(17, false, true); else LJMD_LOOP(17, true, true); }
+                else if (nu == 17)    { if (all4) LJMD_LOOP(17, false, false); else LJMD_LOOP(17, true, false); }
+                else if (nu == 18 && inner) { if (all4) LJMD_LOOP(18, false, true); else LJMD_LOOP(18, true, true); }
+                else if (nu == 18)    { if (all4) LJMD_LOOP(18, false, false); else LJMD_LOOP(18, true, false); }
                 else if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
                 else if (nu == 0)     { if (all4) LJMD_LOOP(0, false, false); else LJMD_LOOP(0, true, false); }
                 else if (nu == 1)     { if (all4) LJMD_LOOP(1, false, false); else LJMD_LOOP(1, true, false); }
