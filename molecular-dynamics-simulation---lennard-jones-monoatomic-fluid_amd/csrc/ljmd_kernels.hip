@@ -300,9 +300,11 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
     // NU == 8: the common image is n = 0 on all three axes: d = xi - xj (1 instruction per axis)
     // NU == 16 + a: every axis has a common image and only axis a's is non-zero: one subtraction more on that
     // axis, none on the others ((d - 0.0) == d, so this is the NU == 0 result bit for bit)
-    constexpr bool gx = NU < 8 && (NU & 1), gy = NU < 8 && (NU & 2), gz = NU < 8 && (NU & 4);
-    constexpr bool px = NU == 8 || (NU >= 16 && NU != 16), py = NU == 8 || (NU >= 16 && NU != 17),
-                   pz = NU == 8 || (NU >= 16 && NU != 18);
+    // NU == 24 + a: axis a general, the two others with the common image n = 0 (same remark)
+    constexpr bool gx = (NU < 8 && (NU & 1)) || NU == 24, gy = (NU < 8 && (NU & 2)) || NU == 25,
+                   gz = (NU < 8 && (NU & 4)) || NU == 26;
+    constexpr bool px = NU == 8 || (NU >= 16 && NU != 16 && NU != 24), py = NU == 8 || (NU >= 16 && NU != 17 && NU != 25),
+                   pz = NU == 8 || (NU >= 16 && NU != 18 && NU != 26);
     const double dx = px ? (xi - xj) : gx ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
     const double dy = py ? (yi - yj) : gy ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
     const double dz = pz ? (zi - zj) : gz ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
@@ -387,6 +389,10 @@ __device__ __forceinline__ bool uniform_image(double lo, double hi, double L, do
     shift = n * L;                                       // exact for |n| <= 2
     return (tlo > n - 0.5 + 1e-9) && (thi < n + 0.5 - 1e-9) && (fabs(n) <= 2.0);
 }
+
+#ifdef LJMD_VARIANT_STATS
+__device__ unsigned long long g_variant_stats[64];
+#endif
 
 template <int MIN_WAVES, int RT>
 __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
@@ -480,6 +486,10 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 if (nu & 2) sy = 0.0;
                 if (nu & 4) sz = 0.0;
                 if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
+                if (nu == 1 && sy == 0.0 && sz == 0.0) nu = 24;          // one general axis, no image on the others
+                else if (nu == 2 && sx == 0.0 && sz == 0.0) nu = 25;
+                else if (nu == 4 && sx == 0.0 && sy == 0.0) nu = 26;
+                nu = __builtin_amdgcn_readfirstlane(nu);
                 if (nu == 0) {
                     const int nz = __builtin_amdgcn_readfirstlane((sx != 0.0 ? 1 : 0) | (sy != 0.0 ? 2 : 0) | (sz != 0.0 ? 4 : 0));
                     nu = nz == 0 ? 8 : nz == 1 ? 16 : nz == 2 ? 17 : nz == 4 ? 18 : 0;   // none / one axis / several
@@ -521,6 +531,10 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
     column_tile_loop<RT, NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
                                            a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
                 const bool all4 = mb == ((1u << RT) - 1u);
+#ifdef LJMD_VARIANT_STATS
+                if (lane == 0)          // measurement build only (tools/variant_stats.py): row tiles evaluated per class
+                    atomicAdd(&g_variant_stats[(nu & 31) * 2 + (inner ? 1 : 0)], (unsigned long long)__builtin_popcount(mb));
+#endif
                 if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
                 else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
                 else if (nu == 16 && inner) { if (all4) LJMD_LOOP(16, false, true); else LJMD_LOOP(16, true, true); }
@@ -531,6 +545,9 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 else if (nu == 18)    { if (all4) LJMD_LOOP(18, false, false); else LJMD_LOOP(18, true, false); }
                 else if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
                 else if (nu == 0)     { if (all4) LJMD_LOOP(0, false, false); else LJMD_LOOP(0, true, false); }
+                else if (nu == 24)    { if (all4) LJMD_LOOP(24, false, false); else LJMD_LOOP(24, true, false); }
+                else if (nu == 25)    { if (all4) LJMD_LOOP(25, false, false); else LJMD_LOOP(25, true, false); }
+                else if (nu == 26)    { if (all4) LJMD_LOOP(26, false, false); else LJMD_LOOP(26, true, false); }
                 else if (nu == 1)     { if (all4) LJMD_LOOP(1, false, false); else LJMD_LOOP(1, true, false); }
                 else if (nu == 2)     { if (all4) LJMD_LOOP(2, false, false); else LJMD_LOOP(2, true, false); }
                 else if (nu == 4)     { if (all4) LJMD_LOOP(4, false, false); else LJMD_LOOP(4, true, false); }
@@ -1173,3 +1190,15 @@ hipError_t launch_finalize(const FinalizeArgs &a_in, double *fold_scratch, hipSt
 }
 
 }  // namespace ljmdk
+
+#ifdef LJMD_VARIANT_STATS
+extern "C" int ljmd_debug_variant_stats(unsigned long long *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(ljmdk::g_variant_stats), 64 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[64] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(ljmdk::g_variant_stats), z, sizeof z);
+    }
+    return (int)e;
+}
+#endif

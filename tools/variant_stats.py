@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Distribution of the Newton-3 kernel's loop variants over the (row tile, column tile) passes of the bench workload,
+from a measurement build of the library (make -C .../csrc OUT=.../libljmd_stats.so EXTRA=-DLJMD_VARIANT_STATS).
+Also counts, on the host, how many of those passes' pairs are really inside the cutoff."""
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+os.environ["LJMD_LIBRARY"] = str(ROOT / "molecular-dynamics-simulation---lennard-jones-monoatomic-fluid_amd" / "libljmd_stats.so")
+sys.path.insert(0, str(ROOT))
+import ljmd_amd  # noqa: E402,F401
+from ljmd_amd import Engine, synthetic, _lib  # noqa: E402
+
+n = int(os.environ.get("STATS_N", "262144"))
+p, r, v = synthetic.make_config(n)
+lib = _lib.load()
+buf = (C.c_ulonglong * 64)()
+names = {8: "no image", 16: "common image, x only", 17: "common image, y only", 18: "common image, z only",
+         0: "common image, several axes", 24: "x general, others no image", 25: "y general, others no image", 26: "z general, others no image", 1: "x general", 2: "y general", 4: "z general", 7: "all general"}
+with Engine(p) as eng:
+    eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+    eng.compute_forces()
+    for label, steps in (("t = 0 (jittered lattice)", 0), ("after 300 steps (liquid)", 300)):
+        if steps:
+            eng.verlet_steps(steps)
+        lib.ljmd_debug_variant_stats(buf, 1)
+        eng.compute_forces()
+        eng.synchronize()
+        lib.ljmd_debug_variant_stats(buf, 1)
+        tot = sum(buf)
+        pairs_all = n * (n - 1) / 2
+        print(f"== {label}: {tot} (row tile, column tile) passes = {tot * 4096 / pairs_all:.3f} of all unordered pairs "
+              f"(diagonal-tile passes are not counted)")
+        for nu, name in names.items():
+            a, b = buf[nu * 2], buf[nu * 2 + 1]
+            if a + b:
+                print(f"  {name:30s} {100.0 * (a + b) / tot:6.2f} %   of which INNER (no cutoff test) {100.0 * b / tot:6.2f} %")
