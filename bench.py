@@ -229,7 +229,9 @@ def main() -> None:
         # command (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be read from inside the run)
         pmc = ROOT / "profiles" / "r01_final_pmc_hbm_traffic.json"
         if world == 1 and n == N_PARTICLES and pmc.exists():
-            k = json.loads(pmc.read_text())["kernels"].get("ljmdk::" + kernel_name + "<3>") or {}
+            kernels = json.loads(pmc.read_text())["kernels"]
+            hits = [val for key, val in kernels.items() if key.startswith("ljmdk::" + kernel_name + "<")]
+            k = max(hits, key=lambda val: val["hbm_bytes_per_launch"]) if hits else {}   # the template instance that ran
             if k:
                 line["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
                 line["roofline"]["traffic_source"] = "profiles/r01_final_pmc_hbm_traffic.json"
