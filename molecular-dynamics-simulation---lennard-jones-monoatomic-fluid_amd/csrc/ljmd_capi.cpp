@@ -681,7 +681,10 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     h->sort_enabled = env_int("LJMD_SORT", 1) != 0 && n >= env_int("LJMD_SORT_MIN_N", 1024);
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
     h->force_collectives = env_int("LJMD_FORCE_COLLECTIVES", 0) != 0;
-    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", 20));
+    // tiles loosen as the particles diffuse (liquid at n = 262144: pair kernel +2.8 % after 10 steps, +5.6 % after 20,
+    // +9 % after 40 -- tools/resort_sweep.py) while one re-sort costs ~1.25 ms there: the larger the system, the
+    // sooner a re-sort pays for itself (pair time per rank ~ n^2 / G, sort time ~ n / G: the ratio depends on n only)
+    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", n >= 1000000 ? 5 : n >= 131072 ? 10 : 20));
     h->ncell = std::max(1, std::min(1023, (int)std::floor(box_length / 1.2)));
     h->kd_sort = env_int("LJMD_SORT_KD", 1) != 0;
     std::vector<int> kd_offsets;
