@@ -78,6 +78,9 @@ struct ljmd {
     double *d_slab = nullptr;     // [nslab_max][3][P]
     double *d_wg_part = nullptr;  // [n_wg_max][2]
     double *d_fold = nullptr;     // [kFoldBlocks][2]
+    unsigned *d_ticket = nullptr; // blocks-done counter of the kick kernel with the finalize folded in
+    bool fuse_small = true;       // LJMD_FUSE: boxes inside the drift kernel, finalize inside the kick kernel
+    bool boxes_valid = false;     // d_bbox already holds the boxes of the current positions (written by the drift kernel)
     double *d_ke_part = nullptr;  // [n_ke][3]
     double *d_ring = nullptr;     // [kRingCap][kPartialStride]
     unsigned *d_ring_pos = nullptr;
@@ -249,6 +252,8 @@ IntegrateArgs integrate_args(ljmd_t *h)
     a.v = h->d_v;
     a.a = h->d_a;
     a.fsum = needs_force_exchange(h) ? h->d_frecv : h->d_fpart;
+    a.bbox = nullptr;
+    a.ticket = nullptr;
     a.ke_part = h->d_ke_part;
     a.rows = h->P;
     a.P = h->P;
@@ -400,7 +405,8 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
     if (fast) {
         GeometryArgs ga = geometry_args(h);
         if (!h->use_n3) ga.mask_far = nullptr;
-        LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
+        if (!h->boxes_valid) LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
+        h->boxes_valid = false;                    // good for this evaluation only
         LJMD_HIP(h, launch_tile_mask(ga, h->stream));
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
@@ -465,8 +471,14 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
             if (rc_ != LJMD_OK) return rc_;
         }
     }
-    LJMD_HIP(h, launch_kick(integrate_args(h), kick, h->stream));
-    LJMD_HIP(h, launch_finalize(finalize_args(h, h->pending_n_wg, kick, h->pending_scale), h->d_fold, h->stream));
+    if (h->fuse_small && h->pending_n_wg <= 4096) {
+        IntegrateArgs ia = integrate_args(h);
+        ia.ticket = h->d_ticket;
+        LJMD_HIP(h, launch_kick_finalize(ia, finalize_args(h, h->pending_n_wg, kick, h->pending_scale), kick, h->stream));
+    } else {
+        LJMD_HIP(h, launch_kick(integrate_args(h), kick, h->stream));
+        LJMD_HIP(h, launch_finalize(finalize_args(h, h->pending_n_wg, kick, h->pending_scale), h->d_fold, h->stream));
+    }
     if (q) LJMD_HIP(h, hipEventRecord(q->e[4], h->stream));
     h->ring_issued++;
     h->have_accel = true;
@@ -499,7 +511,12 @@ int enqueue_drift(ljmd_t *h, EventSet *q)
         LJMD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gather_done, 0));
         h->gather_done_for_step = true;
     } else {
-        LJMD_HIP(h, launch_drift_kick(integrate_args(h), 0, h->stream));
+        IntegrateArgs ia = integrate_args(h);
+        // single rank, no re-sort behind this kernel: the drift kernel's waves are the tiles -- let them write
+        // the bounding boxes of the new positions and skip tile_boxes_kernel in the force evaluation that follows
+        h->boxes_valid = h->fuse_small && h->G == 1 && !resort_now && fast_path_ok(h);
+        if (h->boxes_valid) ia.bbox = h->d_bbox;
+        LJMD_HIP(h, launch_drift_kick(ia, 0, h->stream));
     }
     h->positions_compact = true;  // freshly wrapped into [0, L]
     if (h->sort_enabled && fast_path_ok(h) && ++h->steps_since_sort >= h->resort_every)
@@ -563,7 +580,7 @@ void release(ljmd_t *h)
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv,
-                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold};
+                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -681,6 +698,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     h->sort_enabled = env_int("LJMD_SORT", 1) != 0 && n >= env_int("LJMD_SORT_MIN_N", 1024);
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
     h->force_collectives = env_int("LJMD_FORCE_COLLECTIVES", 0) != 0;
+    h->fuse_small = env_int("LJMD_FUSE", 1) != 0;
     // tiles loosen as the particles diffuse (liquid at n = 262144: pair kernel +2.8 % after 10 steps, +5.6 % after 20,
     // +9 % after 40 -- tools/resort_sweep.py) while one re-sort costs ~1.25 ms there: the larger the system, the
     // sooner a re-sort pays for itself (pair time per rank ~ n^2 / G, sort time ~ n / G: the ratio depends on n only)
@@ -793,6 +811,8 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         if (needs_force_exchange(h)) LJMD_HIP(h, hipMalloc(&h->d_frecv, P3));
         LJMD_HIP(h, hipMalloc(&h->d_ke_part, 3 * (size_t)h->n_ke * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_fold, 2 * (size_t)kFoldBlocks * sizeof(double)));
+        LJMD_HIP(h, hipMalloc(&h->d_ticket, sizeof(unsigned)));
+        LJMD_HIP(h, hipMemsetAsync(h->d_ticket, 0, sizeof(unsigned), h->stream));
         LJMD_HIP(h, hipMalloc(&h->d_ring, (size_t)kRingCap * kPartialStride * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring_pos, sizeof(unsigned)));
         LJMD_HIP(h, hipMalloc(&h->d_bbox, (size_t)h->T * kBoxStride * sizeof(double)));
@@ -837,6 +857,7 @@ void ljmd_destroy(ljmd_t *h) { release(h); }
 int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz,
                    const double *vx, const double *vy, const double *vz)
 {
+    if (h) h->boxes_valid = false;
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_set_state: NULL handle");
     if (!rx || !ry || !rz || !vx || !vy || !vz)
         return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_set_state: NULL array");

@@ -72,6 +72,8 @@ struct IntegrateArgs {
     int rows;               // = P (padding included: it integrates to NaN / 0 harmlessly)
     int P;
     double L, invL, dt, dt_half, dt_sq_half;
+    double *bbox;           // drift kernel, single rank: also emit the tile bounding boxes [P / 64][kBoxStride] (else NULL)
+    unsigned *ticket;       // kick kernel with the finalize folded in: blocks-done counter (else NULL)
 };
 
 // Deterministic reduction of the pair kernels' partial-acceleration slabs into fpart.
@@ -134,6 +136,8 @@ hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, int phase /* 0 all, 1 positions, 2 velocities */, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);
 hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
+// kick + finalize in one launch: the last block to finish folds the partials (needs a.ticket, f.n_wg <= 4096)
+hipError_t launch_kick_finalize(const IntegrateArgs &a, const FinalizeArgs &f, bool kick, hipStream_t s);
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, double *fold_scratch /* [2 * kFoldBlocks] or NULL */, hipStream_t s);
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);

@@ -852,11 +852,12 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
 // PHASE 0: everything.  Multi-rank runs split it so that the position all-gather can start as early as
 // possible: PHASE 1 = positions (r, wrap, ru), PHASE 2 = the velocity half-kick, which then runs
 // while the all-gather is in flight on the communication stream.  Same arithmetic either way.
-template <int PHASE>
+template <int PHASE, bool BOXES = false>
 __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.rows) return;
+    if (i >= a.rows) return;                     // rows = P is a multiple of the block size: whole waves only
+    double rn[3];
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         const size_t o = (size_t)ax * a.P + i;
@@ -869,8 +870,20 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
             d = d - a.L * __builtin_round(d * a.invL);
             a.r[o] = r1;
             a.ru[o] = a.ru[o] + d;
+            rn[ax] = r1;
         }
         if constexpr (PHASE != 1) a.v[o] = v0 + acc * a.dt_half;
+    }
+    if constexpr (BOXES && PHASE != 2) {
+        // single rank: the wave holds exactly one tile -- emit its bounding box here (same values, same
+        // reductions as tile_boxes_kernel) and save that launch
+        const double lx = wave_min(rn[0]), ly = wave_min(rn[1]), lz = wave_min(rn[2]);
+        const double hx = wave_max(rn[0]), hy = wave_max(rn[1]), hz = wave_max(rn[2]);
+        if ((threadIdx.x & 63) == 0) {
+            double *o = a.bbox + (size_t)(i >> 6) * kBoxStride;
+            o[0] = lx; o[1] = ly; o[2] = lz;
+            o[3] = hx; o[4] = hy; o[5] = hz;
+        }
     }
 }
 
@@ -1019,9 +1032,8 @@ __global__ __launch_bounds__(kBlock) void fold_partials_kernel(const double *wg_
 // The host (ljmd_combine_scalars) adds the ranks in rank order and applies the
 // prefactors and tail constants.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void finalize_kernel(FinalizeArgs a)
+__device__ __forceinline__ void finalize_body(const FinalizeArgs &a, double *red /* [5 * kWavesPerBlock] */)
 {
-    __shared__ double red[5 * kWavesPerBlock];
     double v[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int w = threadIdx.x; w < a.n_wg; w += kBlock) {
         v[0] += a.wg_part[2 * (size_t)w];
@@ -1046,6 +1058,53 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(FinalizeArgs a)
         rec[7] = 0.0;
         *a.ring_pos = pos + 1;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void finalize_kernel(FinalizeArgs a)
+{
+    __shared__ double red[5 * kWavesPerBlock];
+    finalize_body(a, red);
+}
+
+// K3b + K4 in one launch (small and medium systems, where every launch costs ~4 us of the step): the kick
+// kernel's blocks take a ticket when their kinetic-energy partial is out; the block that draws the last
+// ticket runs the finalize body -- the same code, hence the same summation order and the same bits.
+template <bool KICK>
+__global__ __launch_bounds__(kBlock) void kick_finalize_kernel(IntegrateArgs a, FinalizeArgs f)
+{
+    __shared__ double red[5 * kWavesPerBlock];
+    __shared__ bool last;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double k2[3] = {0.0, 0.0, 0.0};
+    if (i < a.rows) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const size_t o = (size_t)ax * a.P + i;
+            const double acc = 24.0 * a.fsum[o];
+            a.a[o] = acc;
+            if constexpr (KICK) {
+                const double v1 = a.v[o] + acc * a.dt_half;
+                a.v[o] = v1;
+                k2[ax] = v1 * v1;
+            }
+        }
+    }
+    if constexpr (KICK) block_sum<3>(k2, red);
+    if (threadIdx.x == 0) {
+        if constexpr (KICK) {
+            double *w = a.ke_part + 3 * (size_t)blockIdx.x;
+            w[0] = k2[0];
+            w[1] = k2[1];
+            w[2] = k2[2];
+        }
+        __threadfence();                                   // this block's partial is visible device-wide ...
+        last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;   // ... before its ticket is
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                       // the other blocks' partials, fresh from L2
+    finalize_body(f, red);
+    if (threadIdx.x == 0) *a.ticket = 0u;                  // ready for the next launch (stream-ordered)
 }
 
 // ===========================================================================
@@ -1140,6 +1199,8 @@ hipError_t launch_drift_kick(const IntegrateArgs &a, int phase, hipStream_t s)
         hipLaunchKernelGGL(drift_kick_kernel<1>, grid, dim3(kBlock), 0, s, a);
     else if (phase == 2)
         hipLaunchKernelGGL(drift_kick_kernel<2>, grid, dim3(kBlock), 0, s, a);
+    else if (a.bbox)
+        hipLaunchKernelGGL((drift_kick_kernel<0, true>), grid, dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(drift_kick_kernel<0>, grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
@@ -1162,6 +1223,16 @@ hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s)
         hipLaunchKernelGGL(kick_kernel<true>, grid, dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL(kick_kernel<false>, grid, dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_kick_finalize(const IntegrateArgs &a, const FinalizeArgs &f, bool kick, hipStream_t s)
+{
+    const dim3 grid((a.rows + kBlock - 1) / kBlock);
+    if (kick)
+        hipLaunchKernelGGL(kick_finalize_kernel<true>, grid, dim3(kBlock), 0, s, a, f);
+    else
+        hipLaunchKernelGGL(kick_finalize_kernel<false>, grid, dim3(kBlock), 0, s, a, f);
     return hipGetLastError();
 }
 

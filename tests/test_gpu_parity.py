@@ -669,3 +669,22 @@ def test_config2_10000_steps_vs_the_references_own_series():
     Pm = np.mean([observables(p, a, b, c)[2] for a, b, c in mine[5000:, :3]])
     Pr = np.mean([observables(p, a, b, c)[2] for a, b, c in ref[5000:, :3]])
     assert abs(Pm / Pr - 1.0) < 2e-2
+
+
+@pytest.mark.parametrize("n", [500, 4096, 32768])
+def test_fused_launches_are_bitwise_equal_to_the_separate_kernels(n, monkeypatch):
+    """LJMD_FUSE=1 (default): tile boxes written by the drift kernel, finalize folded into the kick kernel through
+    a last-block ticket.  Same values, same reductions, same order -> the same bits as the separate launches."""
+    p, r, v = synthetic.make_config(n, seed=9)
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("LJMD_FUSE", fuse)
+        with Engine(p) as eng:
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            e0 = eng.compute_forces()
+            sc = np.stack(eng.verlet_steps(45))          # crosses re-sorts for n >= 1024
+            e1 = eng.compute_forces()                    # a force call right after steps: boxes must be recomputed
+            st = eng.get_state()
+            out.append((e0, sc, e1, np.stack([np.stack(st[k]) for k in ("r", "ru", "v", "a")])))
+    assert out[0][0] == out[1][0] and out[0][2] == out[1][2]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3])
