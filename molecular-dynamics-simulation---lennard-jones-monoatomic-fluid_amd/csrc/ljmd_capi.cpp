@@ -119,6 +119,8 @@ struct ljmd {
     double r_split = 5.0;             // LJMD_FP32_SPLIT: boxes closer than this stay fp64
     // reduced raw accelerations: fpart [G or 1][3][P]; frecv [3][P] = reduce-scatter result (G > 1, Newton-3)
     double *d_fpart = nullptr, *d_frecv = nullptr;
+    double *d_fall = nullptr;         // [G][3][P] blocks received in the all-to-all form of the force exchange
+    bool exchange_alltoall = false;   // LJMD_FORCE_EXCHANGE=alltoall: direct sends + local rank-order sum
     bool forces_pending = false;      // pair kernel + slab reduction enqueued, kick not yet
     bool external_force_exchange = false;   // tests: the caller sums fpart over ranks into frecv
     int pending_n_wg = 0;
@@ -463,9 +465,24 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
             const int rc_ = comm_begin(h);
             if (rc_ != LJMD_OK) return rc_;
         }
-        const ncclResult_t r = ncclReduceScatter(h->d_fpart, h->d_frecv, 3 * (size_t)h->P, ncclDouble, ncclSum,
-                                                 h->comm, cs ? h->comm_stream : h->stream);
-        if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclReduceScatter failed: %s", ncclGetErrorString(r));
+        const hipStream_t xs = cs ? h->comm_stream : h->stream;
+        const size_t blk = 3 * (size_t)h->P;
+        if (h->exchange_alltoall) {
+            // every rank sends block g of its fpart straight to rank g (one xGMI link per peer on the fully
+            // connected mesh) and adds the G blocks it receives in rank order: explicit, reproducible sum order
+            ncclResult_t r = ncclGroupStart();
+            for (int g = 0; g < h->G && r == ncclSuccess; ++g) {
+                r = ncclSend(h->d_fpart + (size_t)g * blk, blk, ncclDouble, g, h->comm, xs);
+                if (r == ncclSuccess) r = ncclRecv(h->d_fall + (size_t)g * blk, blk, ncclDouble, g, h->comm, xs);
+            }
+            const ncclResult_t e = ncclGroupEnd();
+            if (r == ncclSuccess) r = e;
+            if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "force all-to-all failed: %s", ncclGetErrorString(r));
+            LJMD_HIP(h, launch_sum_blocks(h->d_fall, h->d_frecv, h->G, (int)blk, xs));
+        } else {
+            const ncclResult_t r = ncclReduceScatter(h->d_fpart, h->d_frecv, blk, ncclDouble, ncclSum, h->comm, xs);
+            if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclReduceScatter failed: %s", ncclGetErrorString(r));
+        }
         if (cs) {
             const int rc_ = comm_end(h);
             if (rc_ != LJMD_OK) return rc_;
@@ -581,7 +598,7 @@ void release(ljmd_t *h)
         for (auto &e : q.e) (void)hipEventDestroy(e);
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
-                   h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv,
+                   h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv, h->d_fall,
                    h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -701,6 +718,10 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
     h->force_collectives = env_int("LJMD_FORCE_COLLECTIVES", 0) != 0;
     h->fuse_small = env_int("LJMD_FUSE", 1) != 0;
+    {
+        const char *fx = std::getenv("LJMD_FORCE_EXCHANGE");
+        h->exchange_alltoall = fx && std::strcmp(fx, "alltoall") == 0;
+    }
     // tiles loosen as the particles diffuse (liquid at n = 262144: pair kernel +2.8 % after 10 steps, +5.6 % after 20,
     // +9 % after 40 -- tools/resort_sweep.py) while one re-sort costs ~1.25 ms there: the larger the system, the
     // sooner a re-sort pays for itself (pair time per rank ~ n^2 / G, sort time ~ n / G: the ratio depends on n only)
@@ -811,6 +832,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         }
         LJMD_HIP(h, hipMalloc(&h->d_fpart, P3 * (needs_force_exchange(h) ? h->G : 1)));
         if (needs_force_exchange(h)) LJMD_HIP(h, hipMalloc(&h->d_frecv, P3));
+        if (needs_force_exchange(h) && h->exchange_alltoall) LJMD_HIP(h, hipMalloc(&h->d_fall, P3 * h->G));
         LJMD_HIP(h, hipMalloc(&h->d_ke_part, 3 * (size_t)h->n_ke * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_fold, 2 * (size_t)kFoldBlocks * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ticket, sizeof(unsigned)));

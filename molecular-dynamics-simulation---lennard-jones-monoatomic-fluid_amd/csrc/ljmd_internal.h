@@ -139,6 +139,8 @@ hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
 // kick + finalize in one launch: the last block to finish folds the partials (needs a.ticket, f.n_wg <= 4096)
 hipError_t launch_kick_finalize(const IntegrateArgs &a, const FinalizeArgs &f, bool kick, hipStream_t s);
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);
+// out[i] = blocks[0][i] + blocks[1][i] + ... + blocks[G-1][i], i < len (left to right: the order is part of the result)
+hipError_t launch_sum_blocks(const double *blocks, double *out, int G, int len, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, double *fold_scratch /* [2 * kFoldBlocks] or NULL */, hipStream_t s);
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);

@@ -1236,6 +1236,21 @@ hipError_t launch_kick_finalize(const IntegrateArgs &a, const FinalizeArgs &f, b
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(kBlock) void sum_blocks_kernel(const double *blocks, double *out, int G, int len)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= len) return;
+    double t = blocks[i];
+    for (int g = 1; g < G; ++g) t += blocks[(size_t)g * len + i];
+    out[i] = t;
+}
+
+hipError_t launch_sum_blocks(const double *blocks, double *out, int G, int len, hipStream_t s)
+{
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3((len + kBlock - 1) / kBlock), dim3(kBlock), 0, s, blocks, out, G, len);
+    return hipGetLastError();
+}
+
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(kinetic_fused_kernel, dim3((a.rows + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);

@@ -137,8 +137,8 @@ def test_rccl_communicator_single_rank():
         assert np.array_equal(np.stack(sc), np.stack(ref.verlet_steps(5)))
 
 
-@pytest.mark.parametrize("overlap", ["1", "0"])
-def test_rccl_collectives_really_issued_by_the_engine(monkeypatch, overlap):
+@pytest.mark.parametrize("overlap,exchange", [("1", "reducescatter"), ("0", "reducescatter"), ("1", "alltoall"), ("0", "alltoall")])
+def test_rccl_collectives_really_issued_by_the_engine(monkeypatch, overlap, exchange):
     """LJMD_FORCE_COLLECTIVES=1: a 1-rank engine goes through the multi-rank code path for real --
     ncclAllGather (in place) between the position update and the pair kernel, ncclReduceScatter of the
     partial accelerations into the receive buffer the kick kernel reads -- both enqueued by the library
@@ -156,6 +156,9 @@ def test_rccl_collectives_really_issued_by_the_engine(monkeypatch, overlap):
         st_ref = ref.get_state()
     monkeypatch.setenv("LJMD_FORCE_COLLECTIVES", "1")
     monkeypatch.setenv("LJMD_OVERLAP_EXCHANGE", overlap)
+    # exchange=alltoall: ncclSend/ncclRecv of the partial-acceleration blocks inside one group + a local
+    # rank-order sum, instead of ncclReduceScatter
+    monkeypatch.setenv("LJMD_FORCE_EXCHANGE", exchange)
     with Engine(p) as eng:
         eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         with pytest.raises(ljmd_amd.LjmdError, match="ljmd_comm_init"):
