@@ -199,7 +199,9 @@ def main() -> None:
                        "particles": n, "sharding": (f"rows/{world}" + (" (REHEARSAL: all ranks on one device)" if share else "")) if world > 1 else "single GPU",
                        "exchange": ("RCCL all-gather + reduce-scatter inside libljmd.so" if exchange == "rccl"
                                     else "HOST-STAGED FALLBACK (RCCL init failed): PCIe + gloo") if world > 1 else "none",
-                       "unordered_pairs_per_step": pairs},
+                       "unordered_pairs_per_step": pairs,
+                       **({"force_exchange": os.environ.get("LJMD_FORCE_EXCHANGE", "reducescatter"),
+                           "overlap_exchange": os.environ.get("LJMD_OVERLAP_EXCHANGE", "1")} if world > 1 else {})},
             "pair_interactions_per_sec": pairs * steps_per_s,
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": None,
