@@ -597,18 +597,18 @@ __device__ __forceinline__ float dpp_rotate_f32(float v)
     return __int_as_float(i);
 }
 
-template <bool UNIFORM>
+// GEN: bit k set = axis k needs the general minimum image; clear = its common image shift is already folded
+// into the row offsets (0 = the former UNIFORM, 7 = all general)
+template <int GEN>
 __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float xj, float yj, float zj,
                                             float Lf, float invLf, float rc2f,
                                             float &ax, float &ay, float &az, float &jx, float &jy, float &jz,
                                             float &s12, float &s6)
 {
     float dx = xi - xj, dy = yi - yj, dz = zi - zj;
-    if constexpr (!UNIFORM) {
-        dx = fmaf(-Lf, __builtin_rintf(dx * invLf), dx);
-        dy = fmaf(-Lf, __builtin_rintf(dy * invLf), dy);
-        dz = fmaf(-Lf, __builtin_rintf(dz * invLf), dz);
-    }
+    if constexpr (GEN & 1) dx = fmaf(-Lf, __builtin_rintf(dx * invLf), dx);
+    if constexpr (GEN & 2) dy = fmaf(-Lf, __builtin_rintf(dy * invLf), dy);
+    if constexpr (GEN & 4) dz = fmaf(-Lf, __builtin_rintf(dz * invLf), dz);
     const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     if (r2 < rc2f) {
         const float u = __builtin_amdgcn_rcpf(r2);
@@ -626,7 +626,7 @@ __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float 
     }
 }
 
-template <bool UNIFORM, bool MASKED>
+template <int GEN, bool MASKED>
 __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], const float (&py)[kRowTiles],
                                                 const float (&pz)[kRowTiles], float (&fx)[kRowTiles],
                                                 float (&fy)[kRowTiles], float (&fz)[kRowTiles],
@@ -638,7 +638,7 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k)
             if (!MASKED || ((mb >> k) & 1u))
-                pair_n3_f32<UNIFORM>(px[k], py[k], pz[k], xj, yj, zj, Lf, invLf, rc2f, fx[k], fy[k], fz[k],
+                pair_n3_f32<GEN>(px[k], py[k], pz[k], xj, yj, zj, Lf, invLf, rc2f, fx[k], fy[k], fz[k],
                                      jx, jy, jz, s12, s6);
         xj = dpp_rotate_f32(xj); yj = dpp_rotate_f32(yj); zj = dpp_rotate_f32(zj);
         jx = dpp_rotate_f32(jx); jy = dpp_rotate_f32(jy); jz = dpp_rotate_f32(jz);
@@ -708,9 +708,13 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
             const bool ux = uniform_image(glo[0] - cbx[3], ghi[0] - cbx[0], a.L, a.invL, sx);
             const bool uy = uniform_image(glo[1] - cbx[4], ghi[1] - cbx[1], a.L, a.invL, sy);
             const bool uz = uniform_image(glo[2] - cbx[5], ghi[2] - cbx[2], a.L, a.invL, sz);
-            const bool uni = __builtin_amdgcn_readfirstlane((int)(ux && uy && uz)) != 0;
-            if (!uni) sx = sy = sz = 0.0;
-
+            // per axis: common image (shift folded below) or general; two or more general axes -> all general
+            int gen = __builtin_amdgcn_readfirstlane((ux ? 0 : 1) | (uy ? 0 : 2) | (uz ? 0 : 4));
+            if (gen & 1) sx = 0.0;
+            if (gen & 2) sy = 0.0;
+            if (gen & 4) sz = 0.0;
+            if (gen != 0 && gen != 1 && gen != 2 && gen != 4) gen = 7;   // (a folded shift on an axis that is then
+                                                                          //  also treated generally is harmless)
             const int gj = (a.G == 1) ? 0 : c / a.TB;
             const double *cb = a.pos + (size_t)gj * 3 * P + (size_t)(c - gj * a.TB) * kTile + lane;
             const float xj = (float)(cb[0] - ccx), yj = (float)(cb[P] - ccy), zj = (float)(cb[2 * P] - ccz);
@@ -725,14 +729,15 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
                 fx[k] = fy[k] = fz[k] = 0.0f;
             }
             float jx = 0.0f, jy = 0.0f, jz = 0.0f, t12 = 0.0f, t6 = 0.0f;
-            if (mb == kAllRows && uni)
-                column_loop_f32<true, false>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
-            else if (mb == kAllRows)
-                column_loop_f32<false, false>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
-            else if (uni)
-                column_loop_f32<true, true>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
-            else
-                column_loop_f32<false, true>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6);
+#define LJMD_LOOP32(GEN_, MASKED_)                                                                              \
+    column_loop_f32<GEN_, MASKED_>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6)
+            const bool all4 = mb == kAllRows;
+            if (gen == 0)      { if (all4) LJMD_LOOP32(0, false); else LJMD_LOOP32(0, true); }
+            else if (gen == 1) { if (all4) LJMD_LOOP32(1, false); else LJMD_LOOP32(1, true); }
+            else if (gen == 2) { if (all4) LJMD_LOOP32(2, false); else LJMD_LOOP32(2, true); }
+            else if (gen == 4) { if (all4) LJMD_LOOP32(4, false); else LJMD_LOOP32(4, true); }
+            else               { if (all4) LJMD_LOOP32(7, false); else LJMD_LOOP32(7, true); }
+#undef LJMD_LOOP32
 #pragma unroll
             for (int k = 0; k < kRowTiles; ++k) {
                 ax[k] += (double)fx[k];
