@@ -1119,7 +1119,7 @@ __global__ __launch_bounds__(kBlock) void kick_finalize_kernel(IntegrateArgs a, 
 //   d = x_j - x_i ; d -= L * rint(d / L)      (np.rint = half-to-even; a true division)
 //   r = sqrt(dx*dx + dy*dy + dz*dz)           (unfused, correctly rounded sqrt)
 //   if r < rmax: hist[int(r / dr)] += 2       (i<j pairs, weight 2)
-// evaluated here for every ORDERED pair with weight 1 (the arithmetic is symmetric in i, j).
+// evaluated here for every unordered pair (j > i) once, with weight 2 (the arithmetic is symmetric in i, j).
 // One thread per i, j broadcast through scalar loads, histogram in LDS (ds_add_u32), one
 // 64-bit global atomic per bin and block; integer sums are order independent.
 // ===========================================================================
@@ -1131,16 +1131,19 @@ __global__ __launch_bounds__(kBlock) void rdf_histogram_kernel(RdfArgs a)
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < a.n;
     const double xi = live ? a.x[i] : 0.0, yi = live ? a.y[i] : 0.0, zi = live ? a.z[i] : 0.0;
-    const int j0 = blockIdx.y * a.chunk, j1 = min(j0 + a.chunk, a.n);
+    // every unordered pair ONCE (j > i) with weight 2, as the reference counts (d_ji = -d_ij and rint is odd, so
+    // r and the bin are the same either way): column chunks entirely below this block's rows have nothing to do
+    const int i_first = blockIdx.x * kBlock;
+    const int j0 = max(blockIdx.y * a.chunk, i_first + 1), j1 = min((blockIdx.y + 1) * a.chunk, a.n);
     for (int j = j0; j < j1; ++j) {
         double dx = a.x[j] - xi, dy = a.y[j] - yi, dz = a.z[j] - zi;
         dx = dx - a.L * __builtin_rint(dx / a.L);
         dy = dy - a.L * __builtin_rint(dy / a.L);
         dz = dz - a.L * __builtin_rint(dz / a.L);
         const double r = __builtin_sqrt(dx * dx + dy * dy + dz * dz);
-        if (live && j != i && r < a.rmax) {
+        if (live && j > i && r < a.rmax) {
             const int bin = (int)(r / a.dr);
-            if (bin < a.nbins) atomicAdd(&lhist[bin], 1u);
+            if (bin < a.nbins) atomicAdd(&lhist[bin], 2u);
         }
     }
     __syncthreads();
