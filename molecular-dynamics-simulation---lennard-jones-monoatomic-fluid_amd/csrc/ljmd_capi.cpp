@@ -1503,6 +1503,8 @@ int ljmd_rdf_histogram(int32_t n, const double *x, const double *y, const double
         a.L = box_length;
         a.rmax = rmax;
         a.dr = rmax / nbins;                         // as the reference: dr = rmax / nbins
+        a.invL = 1.0 / box_length;
+        a.inv_dr = 1.0 / a.dr;
         const int row_blocks = (n + kBlock - 1) / kBlock;
         int ns = std::max(1, std::min((kTargetWorkgroups + row_blocks - 1) / row_blocks, (n + 63) / 64));
         a.chunk = (n + ns - 1) / ns;

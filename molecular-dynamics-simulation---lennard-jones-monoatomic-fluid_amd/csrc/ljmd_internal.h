@@ -119,6 +119,7 @@ struct RdfArgs {
     unsigned long long *hist;      // [nbins] ordered-pair counts (added to)
     int n, nbins, chunk;           // chunk = j per grid.y slice
     double L, rmax, dr;
+    double invL, inv_dr;           // 1 / L, 1 / dr: fast paths of the two divisions (exact path kept for near-ties)
 };
 
 struct SortArgs {

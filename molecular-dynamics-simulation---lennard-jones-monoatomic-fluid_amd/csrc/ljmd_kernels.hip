@@ -1123,6 +1123,17 @@ __global__ __launch_bounds__(kBlock) void kick_finalize_kernel(IntegrateArgs a, 
 // One thread per i, j broadcast through scalar loads, histogram in LDS (ds_add_u32), one
 // 64-bit global atomic per bin and block; integer sums are order independent.
 // ===========================================================================
+// rint(d / L) without the division: d * (1/L) is within 2 ulp of the true quotient, so its nearest integer is the
+// reference's unless the product sits within 1e-9 of a half-integer -- then (practically never) the true
+// division decides.  Same integer, hence the same bits downstream.
+__device__ __forceinline__ double rdf_image(double d, double L, double invL)
+{
+    const double q = d * invL;
+    double n = __builtin_rint(q);
+    if (fabs(q - n) > 0.5 - 1e-9) n = __builtin_rint(d / L);
+    return n;
+}
+
 __global__ __launch_bounds__(kBlock) void rdf_histogram_kernel(RdfArgs a)
 {
     extern __shared__ unsigned lhist[];
@@ -1137,12 +1148,15 @@ __global__ __launch_bounds__(kBlock) void rdf_histogram_kernel(RdfArgs a)
     const int j0 = max(blockIdx.y * a.chunk, i_first + 1), j1 = min((blockIdx.y + 1) * a.chunk, a.n);
     for (int j = j0; j < j1; ++j) {
         double dx = a.x[j] - xi, dy = a.y[j] - yi, dz = a.z[j] - zi;
-        dx = dx - a.L * __builtin_rint(dx / a.L);
-        dy = dy - a.L * __builtin_rint(dy / a.L);
-        dz = dz - a.L * __builtin_rint(dz / a.L);
+        dx = dx - a.L * rdf_image(dx, a.L, a.invL);
+        dy = dy - a.L * rdf_image(dy, a.L, a.invL);
+        dz = dz - a.L * rdf_image(dz, a.L, a.invL);
         const double r = __builtin_sqrt(dx * dx + dy * dy + dz * dz);
         if (live && j > i && r < a.rmax) {
-            const int bin = (int)(r / a.dr);
+            // int(r / dr): the product with 1/dr decides unless it lands within 1e-9 of an integer
+            const double q = r * a.inv_dr;
+            int bin = (int)q;
+            if (q - (double)bin < 1e-9 || (double)(bin + 1) - q < 1e-9) bin = (int)(r / a.dr);
             if (bin < a.nbins) atomicAdd(&lhist[bin], 2u);
         }
     }

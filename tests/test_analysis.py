@@ -71,3 +71,23 @@ def test_rdf_gpu_histogram_bit_exact_vs_oracle_all_particles(oracle):
     rc, g = analysis.compute_rdf(r[None, 0], r[None, 1], r[None, 2], p.box_length, nbins=400, subsample=False)
     assert abs(g[-50:].mean() - 1.0) < 5e-3                      # ideal-gas limit at r ~ L/2 (lattice ripples remain)
     assert g[:9].sum() == 0.0 and g[9:16].sum() > 0.0                # first shell of the jittered lattice at 1.08 sigma
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,rmax_frac,nbins", [(8.0, 0.5, 40), (10.0, 0.5, 50), (7.3, 0.37, 64)])
+def test_rdf_gpu_exact_on_ties_and_bin_edges(oracle, L, rmax_frac, nbins):
+    """A perfect 8^3 lattice: coordinate differences are exact multiples of L/8, so d/L hits +-0.5 exactly
+    (the minimum-image tie, np.rint's half-to-even) and r/dr lands exactly on bin edges -- the cases where the
+    kernel's multiply-instead-of-divide fast paths must hand over to the true divisions.  Plus random points
+    snapped to a coarse grid.  Integer histograms must equal the reference's numpy arithmetic exactly."""
+    k = 8
+    g = (np.arange(k) * (L / k))
+    x, y, z = (a.ravel().copy() for a in np.meshgrid(g, g, g, indexing="ij"))
+    rng = np.random.Generator(np.random.PCG64(3))
+    snapped = np.round(rng.uniform(0, L, size=(3, 700)) * 16) / 16 % L       # multiples of 1/16: more exact ties
+    x, y, z = (np.concatenate([a, b]) for a, b in zip((x, y, z), snapped))
+    h_gpu = np.zeros(nbins, dtype=np.uint64)
+    h_ora = np.zeros(nbins, dtype=np.uint64)
+    analysis.rdf_histogram(x, y, z, L, nbins, rmax_frac * L, h_gpu)
+    oracle.rdf_histogram_np(x.copy(), y.copy(), z.copy(), L, nbins, rmax_frac * L, h_ora)
+    assert np.array_equal(h_gpu, h_ora) and h_gpu.sum() > 0
