@@ -378,9 +378,14 @@ def test_bench_configuration_full_parity_vs_oracle_n262144(oracle):
         se, sd, sdd = se + pe, sd + pd, sdd + pdd
     te, td, tdd = oracle.tail_corrections(po)
     ref = (4.0 * (0.5 * se) + te, 24.0 * (0.5 * sd) + td, 24.0 * (0.5 * sdd) + tdd)   # every unordered pair seen twice
+    ao *= 24.0
+    # `pytest -s` shows the measured deviations (profiles/r01_full_parity_n262144.txt is this output)
+    for name, mine, want in zip(("epot", "d_epot", "dd_epot"), (e, d, dd), ref):
+        print(f"{name}: gpu {mine:.16e} oracle {want:.16e} rel.diff {rel(mine, want):.2e}")
+    print(f"accelerations: max|a_gpu - a_oracle| / max|a| = {np.abs(a - ao).max() / np.abs(ao).max():.2e}, "
+          f"rms rel = {np.sqrt(np.mean((a - ao) ** 2)) / np.sqrt(np.mean(ao ** 2)):.2e} ({cores} oracle threads)")
     for name, mine, want in zip(("epot", "d_epot", "dd_epot"), (e, d, dd), ref):
         assert rel(mine, want) <= 1e-12, (name, mine, want, rel(mine, want))
-    ao *= 24.0
     assert np.abs(a - ao).max() <= REL_ACCEL * np.abs(ao).max(), np.abs(a - ao).max() / np.abs(ao).max()
 
 
