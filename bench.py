@@ -123,7 +123,8 @@ def main() -> None:
     # hipStreamSynchronize + hipDeviceSynchronize (Engine.synchronize) is called beside it anyway.
     torch_gpu = torch.cuda.is_available()
     if torch_gpu:
-        torch.cuda.set_device(0 if os.environ.get("LJMD_BENCH_SHARE_DEVICE", "0") == "1" else local_rank)
+        torch.cuda.set_device(0 if os.environ.get("LJMD_BENCH_SHARE_DEVICE", "0") == "1"
+                              else local_rank % max(1, torch.cuda.device_count()))
     import ljmd_amd  # noqa: F401
     from ljmd_amd import Engine, synthetic, distributed
 
@@ -142,7 +143,10 @@ def main() -> None:
     # host-staged exchange.  Never set by the driver; a line produced with them says so in `config`.
     share = os.environ.get("LJMD_BENCH_SHARE_DEVICE", "0") == "1"
     from ljmd_amd import _lib as _abi
-    eng = Engine(p, device=0 if share else local_rank, rank=rank, n_ranks=world,
+    # a launcher may hand every rank its own single visible device (HIP_VISIBLE_DEVICES): then it is device 0
+    ndev = max(1, _abi.load().ljmd_device_count())
+    device = 0 if share else (local_rank if local_rank < ndev else local_rank % ndev)
+    eng = Engine(p, device=device, rank=rank, n_ranks=world,
                  precision_mode=_abi.PRECISION_FP32_FORCE if args.mode == "mixed" else _abi.PRECISION_FP64)
     if os.environ.get("LJMD_BENCH_EXCHANGE", "") == "host" or share:
         exchange = "host"
