@@ -6,6 +6,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+A plain `python bench.py --gpus N` (N > 1, no launcher environment) starts the N ranks itself: the parent
+process -- before it touches torch or the GPU -- runs the torch.distributed.run command above as a CHILD
+process, relays rank 0's JSON line and exits with the child's return code.
+
 One "step" = one full MD step on synthetic input already resident in HBM: drift + wrap +
 half-kick + unwrapped update, all-pairs LJ forces/energy/virial, second half-kick, kinetic
 energy.  For N > 1 the SAME 262 144-particle system is sharded by particle rows (strong
@@ -95,6 +99,36 @@ def cpu_baseline_all_cores(rows: int = 16384) -> dict:
                       f"{os.cpu_count()} visible CPUs); one force evaluation = {N_PARTICLES // rows}x the sample"}
 
 
+def self_launch(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run as a child
+    process (this parent has made no torch / HIP call), relay its output -- the JSON line to stdout, everything
+    else to stderr -- and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] no launcher environment: starting", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    got_line = False
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            print(ln, end="", flush=True)
+            got_line = True
+        else:
+            print(ln, end="", file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and not got_line:
+        print("[bench] the ranks exited cleanly but printed no JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,9 +142,12 @@ def main() -> None:
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and (not launched or os.environ["WORLD_SIZE"] == "1"):
+        raise SystemExit(self_launch(args.gpus))         # parent: nothing below runs here
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launcher and --gpus disagree")
 
     # dmabuf IPC: the only mode the host driver of this pool supports for cross-process device memory (RCCL)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -204,6 +241,7 @@ def main() -> None:
                        "exchange": ("RCCL all-gather + reduce-scatter inside libljmd.so" if exchange == "rccl"
                                     else "HOST-STAGED FALLBACK (RCCL init failed): PCIe + gloo") if world > 1 else "none",
                        "unordered_pairs_per_step": pairs,
+                       **({"rccl_ranks_seen": eng.comm_size()} if world > 1 else {}),
                        **({"force_exchange": os.environ.get("LJMD_FORCE_EXCHANGE", "reducescatter"),
                            "overlap_exchange": os.environ.get("LJMD_OVERLAP_EXCHANGE", "1")} if world > 1 else {})},
             "pair_interactions_per_sec": pairs * steps_per_s,

@@ -209,6 +209,9 @@ void *ljmd_device_ptr(ljmd_t *h, int32_t which, int32_t axis);
 int ljmd_comm_unique_id(char *id_out /* [LJMD_COMM_ID_BYTES] */);
 int ljmd_comm_init(ljmd_t *h, const char *id /* [LJMD_COMM_ID_BYTES] */);
 int ljmd_allgather_positions(ljmd_t *h);
+/* Ranks RCCL itself reports for this handle's communicator (ncclCommCount); 0 = no communicator.
+ * bench.py prints it so that a multi-GPU line proves the collective ran over all ranks. */
+int32_t ljmd_comm_size(const ljmd_t *h);
 /* Copy on the handle's stream, then wait: kind 1 = host->device, 2 = device->host, 3 = device->device.
  * For callers that stage the exchange / force buffers themselves (host-staged fallback, tests). */
 int ljmd_memcpy(ljmd_t *h, void *dst, const void *src, int64_t bytes, int32_t kind);

@@ -72,6 +72,7 @@ PROTOTYPES = {
     "ljmd_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ljmd_comm_init": (C.c_int, [C.c_void_p, C.c_char_p]),
     "ljmd_allgather_positions": (C.c_int, [C.c_void_p]),
+    "ljmd_comm_size": (C.c_int32, [C.c_void_p]),
     "ljmd_synchronize": (C.c_int, [C.c_void_p]),
     "ljmd_memcpy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "ljmd_step_begin": (C.c_int, [C.c_void_p]),

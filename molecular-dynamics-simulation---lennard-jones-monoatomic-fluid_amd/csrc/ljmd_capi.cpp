@@ -1307,6 +1307,14 @@ int ljmd_comm_init(ljmd_t *h, const char *id)
     return LJMD_OK;
 }
 
+int32_t ljmd_comm_size(const ljmd_t *h)
+{
+    if (!h || !h->comm) return 0;
+    int count = 0;
+    if (ncclCommCount(h->comm, &count) != ncclSuccess) return 0;
+    return count;
+}
+
 int ljmd_allgather_positions(ljmd_t *h)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_allgather_positions: NULL handle");

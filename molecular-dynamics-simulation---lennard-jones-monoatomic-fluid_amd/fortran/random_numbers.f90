@@ -2,8 +2,10 @@
 ! random_numbers -- the subtractive lagged generator the reference seeds its initial
 ! velocities with (scripts/base/random_numbers.f90:48-116: Knuth's algorithm in floating
 ! point, modulus 4e6, seed offset 1618033, lags 55/24).  Re-stated so that the GPU init
-! driver draws the SAME velocity sequence: known answers for seed -12345 are
-! 0.6283575, 0.81823825, 0.169642, 0.19663425 (tests/golden/kat.json).
+! driver draws the SAME velocity sequence, bit for bit: the integer state is scaled by the
+! rounded constant 1/4e6 (`fac`, random_numbers.f90:61,112) -- a division by 4e6 is NOT the same
+! double for 1.2e6 of the 4e6 states.  tests/test_init_host.py compares 10^4 draws of THIS module
+! with the oracle (itself pinned to the reference's kat.json).
 !==============================================================================
 module random_numbers
   use define_precision, only: dp_kind, int_kind
@@ -12,6 +14,7 @@ module random_numbers
   public :: random_uniform
 
   real(kind=dp_kind), parameter :: modulus = 4.0d6, seed_offset = 1618033.d0
+  real(kind=dp_kind), parameter :: to_unit = 1.d0 / modulus     ! `fac`: rounded once, then multiplied
   real(kind=dp_kind), save :: table(55)
   integer(kind=int_kind), save :: head = 0, tail = 0
   logical, save :: primed = .false.
@@ -53,7 +56,7 @@ contains
     cur = table(head) - table(tail)
     if (cur < 0.d0) cur = cur + modulus
     table(head) = cur
-    r = cur / modulus
+    r = cur * to_unit
   end function random_uniform
 
 end module random_numbers

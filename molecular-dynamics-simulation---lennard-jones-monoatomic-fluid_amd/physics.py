@@ -217,6 +217,10 @@ class Engine:
         assert len(unique_id) == _lib.COMM_ID_BYTES
         self._ck(self._lib.ljmd_comm_init(self._h, unique_id))
 
+    def comm_size(self) -> int:
+        """Ranks in the engine's RCCL communicator as RCCL reports them (0 = none)."""
+        return int(self._lib.ljmd_comm_size(self._h))
+
     def allgather_positions(self) -> None:
         self._ck(self._lib.ljmd_allgather_positions(self._h))
 

@@ -22,6 +22,7 @@
 !   ref_harness traj  <in.bin> <nsteps> <out.bin>
 !   ref_harness bench <n> <ncalls>
 !   ref_harness kat
+!   ref_harness ran3  <seed> <count> <out.bin>     count draws of the reference's random_uniform, raw fp64
 !
 ! <in.bin>  (stream, little endian): int32 n; real64 L, dt, rc;
 !           rx(n) ry(n) rz(n) vx(n) vy(n) vz(n)
@@ -62,6 +63,11 @@ program ref_harness
     call run_bench(to_int(a1), to_int(a2))
   case ('kat')
     call run_kat()
+  case ('ran3')
+    if (nargs /= 4) call usage()
+    call get_command_argument(2, a1); call get_command_argument(3, a2)
+    call get_command_argument(4, a3)
+    call run_ran3(to_int(a1), to_int(a2), trim(a3))
   case default
     call usage()
   end select
@@ -69,7 +75,7 @@ program ref_harness
 contains
 
   subroutine usage()
-    write(*,'(a)') 'usage: ref_harness force|traj|bench|kat ...'
+    write(*,'(a)') 'usage: ref_harness force|traj|bench|kat|ran3 ...'
     stop 2
   end subroutine usage
 
@@ -190,6 +196,22 @@ contains
     pairs = 0.5d0 * dble(n) * dble(n - 1) * dble(ncalls)
     write(*,'(i0,1x,i0,1x,es16.8,1x,es16.8,1x,es24.16)') n, ncalls, secs, pairs/secs, epot
   end subroutine run_bench
+
+  subroutine run_ran3(seed0, count, fout)
+    integer, intent(in) :: seed0, count
+    character(len=*), intent(in) :: fout
+    integer(kind=int_kind) :: seed
+    real(kind=dp_kind) :: r
+    integer :: iu, k
+    seed = seed0
+    iu = 73
+    open(iu, file=fout, access='stream', form='unformatted', status='replace', action='write')
+    do k = 1, count
+      r = random_uniform(seed)
+      write(iu) r
+    end do
+    close(iu)
+  end subroutine run_ran3
 
   subroutine run_kat()
     real(kind=dp_kind) :: x(3), y(3), z(3)

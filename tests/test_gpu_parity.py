@@ -344,19 +344,15 @@ def test_large_n_properties_262144():
         assert np.abs(a_np - a1[:, i]).max() < 1e-10 * max(np.abs(a_np).max(), 1.0)
 
 
-def test_bench_configuration_full_parity_vs_oracle_n262144(oracle):
-    """The EXACT bench workload (BASELINE config 3: n = 262144, production kernel configuration), one force
-    evaluation, against the CPU oracle over ALL 6.9e10 ordered pairs (OpenMP full-matrix form of the oracle:
-    the reference's per-pair arithmetic, rows independent) -- every acceleration and the three scalars.
-    ~40 s of host time on the GPU box's 16-core CPU share."""
+@pytest.fixture(scope="module")
+def oracle_rows_n262144(oracle):
+    """The CPU oracle over ALL 6.9e10 ordered pairs of the bench workload (OpenMP full-matrix form: the reference's
+    per-pair arithmetic, rows independent): (params, r, v, accelerations[3, n], (epot, d_epot, dd_epot), threads).
+    ~30-40 s of host time on the GPU box's 16-core CPU share; shared by the fp64 and the mixed-precision test."""
     import ctypes
     import os
     n = 262144
     p, r, v = synthetic.make_config(n)
-    with Engine(p) as eng:
-        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
-        e, d, dd = eng.compute_forces()
-        a = np.stack(eng.get_state(("a",))["a"])
     cores = len(os.sched_getaffinity(0))
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -379,7 +375,18 @@ def test_bench_configuration_full_parity_vs_oracle_n262144(oracle):
     te, td, tdd = oracle.tail_corrections(po)
     ref = (4.0 * (0.5 * se) + te, 24.0 * (0.5 * sd) + td, 24.0 * (0.5 * sdd) + tdd)   # every unordered pair seen twice
     ao *= 24.0
-    # `pytest -s` shows the measured deviations (profiles/r01_full_parity_n262144.txt is this output)
+    return p, r, v, ao, ref, cores
+
+
+def test_bench_configuration_full_parity_vs_oracle_n262144(oracle_rows_n262144):
+    """The EXACT bench workload (BASELINE config 3: n = 262144, production kernel configuration), one force
+    evaluation, against the CPU oracle over all ordered pairs -- every acceleration and the three scalars."""
+    p, r, v, ao, ref, cores = oracle_rows_n262144
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e, d, dd = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+    # `pytest -s` shows the measured deviations (profiles/r0N_full_parity_n262144.txt is this output)
     for name, mine, want in zip(("epot", "d_epot", "dd_epot"), (e, d, dd), ref):
         print(f"{name}: gpu {mine:.16e} oracle {want:.16e} rel.diff {rel(mine, want):.2e}")
     print(f"accelerations: max|a_gpu - a_oracle| / max|a| = {np.abs(a - ao).max() / np.abs(ao).max():.2e}, "
@@ -387,6 +394,62 @@ def test_bench_configuration_full_parity_vs_oracle_n262144(oracle):
     for name, mine, want in zip(("epot", "d_epot", "dd_epot"), (e, d, dd), ref):
         assert rel(mine, want) <= 1e-12, (name, mine, want, rel(mine, want))
     assert np.abs(a - ao).max() <= REL_ACCEL * np.abs(ao).max(), np.abs(a - ao).max() / np.abs(ao).max()
+
+
+@pytest.mark.parametrize("split", ["5", "0"])
+def test_mixed_precision_full_parity_vs_oracle_n262144(oracle_rows_n262144, split, monkeypatch):
+    """BASELINE config 5 AT ITS OWN SIZE (n = 262144, LJMD_PRECISION_FP32_FORCE), one force evaluation against the
+    oracle over all ordered pairs.  Written bounds (the reference has no mixed mode; the anchor is its fp64 loop,
+    lj_potential_energy.f90:109-183, through the oracle):
+      r_split = 5 sigma (default): every acceleration within 1e-8 max|a| (the large, near forces stay fp64; a far
+        pair contributes |f| < 24 * 5^-7 with fp32 relative error), scalars within 2e-7 relative;
+      r_split = 0 (every pair outside the own row group in fp32): 2e-5 max|a|, scalars 5e-6."""
+    from ljmd_amd import _lib
+    monkeypatch.setenv("LJMD_FP32_SPLIT", split)
+    p, r, v, ao, ref, _cores = oracle_rows_n262144
+    with Engine(p, precision_mode=_lib.PRECISION_FP32_FORCE) as eng:
+        assert eng.pair_kernel_name() == "pair_n3_f32_kernel"
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e, d, dd = eng.compute_forces()
+        a = np.stack(eng.get_state(("a",))["a"])
+    amax = np.abs(ao).max()
+    for name, mine, want in zip(("epot", "d_epot", "dd_epot"), (e, d, dd), ref):
+        print(f"split {split} {name}: gpu {mine:.16e} oracle {want:.16e} rel.diff {rel(mine, want):.2e}")
+    print(f"split {split} accelerations: max|a_gpu - a_oracle| / max|a| = {np.abs(a - ao).max() / amax:.2e}, "
+          f"rms rel = {np.sqrt(np.mean((a - ao) ** 2)) / np.sqrt(np.mean(ao ** 2)):.2e}; "
+          f"total force / (n max|a|) = {np.abs(a.sum(axis=1)).max() / (p.n * amax):.2e}")
+    tol_a, tol_s = (1e-8, 2e-7) if split == "5" else (2e-5, 5e-6)
+    for name, mine, want in zip(("epot", "d_epot", "dd_epot"), (e, d, dd), ref):
+        assert rel(mine, want) <= tol_s, (name, mine, want, rel(mine, want))
+    assert np.abs(a - ao).max() <= tol_a * amax, np.abs(a - ao).max() / amax
+
+
+def test_mixed_precision_energy_series_vs_oracle_n16384(oracle):
+    """Mixed-precision trajectory against the ORACLE's own velocity-Verlet series (sequential reference arithmetic),
+    n = 16384 (the smallest size the mode accepts), 30 steps from the jittered lattice (~40 s of one host core):
+    Etot(t), T(t) within 1e-9 relative at the default r_split, i.e. indistinguishable from fp64 at the level the
+    README claims (1e-10 at n = 262144 over 20 steps is asserted by the bench line's own energy check)."""
+    from ljmd_amd import _lib
+    n, steps = 16384, 30
+    p, r, v = synthetic.make_config(n, seed=33)
+    po = oracle.derive_params(p.n, p.box_length, p.dt, p.rc)
+    _e, _d, _dd, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    st = {"rx": r[0].copy(), "ry": r[1].copy(), "rz": r[2].copy(), "ux": r[0].copy(), "uy": r[1].copy(),
+          "uz": r[2].copy(), "vx": v[0].copy(), "vy": v[1].copy(), "vz": v[2].copy(), "ax": ax, "ay": ay, "az": az}
+    sc_o = oracle.run_steps(po, steps, st)                       # [steps, 4]: epot, ekin, d_epot, dd_epot
+    out = {}
+    for mode in (_lib.PRECISION_FP64, _lib.PRECISION_FP32_FORCE):
+        with Engine(p, precision_mode=mode) as eng:
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            eng.compute_forces()
+            out[mode] = np.stack(eng.verlet_steps(steps), axis=1)
+    et_o = sc_o[:, 0] + sc_o[:, 1]
+    for mode, tol in ((_lib.PRECISION_FP64, 1e-11), (_lib.PRECISION_FP32_FORCE, 1e-9)):
+        sc = out[mode]
+        d_et = np.max(np.abs(sc[:, 0] + sc[:, 1] - et_o) / np.abs(et_o))
+        d_k = np.max(np.abs(sc[:, 1] - sc_o[:, 1]) / np.abs(sc_o[:, 1]))
+        print(f"mode {mode}: max rel dev Etot {d_et:.2e}, Ekin {d_k:.2e} over {steps} steps vs the oracle")
+        assert d_et <= tol and d_k <= 10 * tol, (mode, d_et, d_k)
 
 
 def test_fast_path_equals_generic_path(golden, monkeypatch):

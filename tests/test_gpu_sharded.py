@@ -182,30 +182,30 @@ def test_rccl_collectives_really_issued_by_the_engine(monkeypatch, overlap, exch
 
 
 def test_bench_two_processes_host_staged_exchange(tmp_path):
-    """bench.py end to end with TWO processes (torch.distributed.run, gloo control plane) sharing this
-    box's single GPU; the exchange is the host-staged safety net because RCCL refuses two ranks on one
-    device.  Checks the multi-process control flow of the very script the driver launches, and that the
-    2-rank trajectory equals the 1-rank one."""
+    """bench.py end to end with TWO processes sharing this box's single GPU, started the way the driver may start
+    it: a PLAIN `python bench.py --gpus 2` with no launcher environment -- bench.py then runs its ranks under
+    torch.distributed.run as a child process and relays rank 0's JSON line.  The exchange is the host-staged
+    safety net because RCCL refuses two ranks on one device.  Checks the multi-process control flow of the very
+    script the driver launches, and that the 2-rank trajectory equals the 1-rank one."""
     import json
     import os
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, LJMD_BENCH_SHARE_DEVICE="1", LJMD_BENCH_EXCHANGE="host")
-    with __import__("socket").socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(LJMD_BENCH_SHARE_DEVICE="1", LJMD_BENCH_EXCHANGE="host")
     common = ["--steps", "4", "--warmup", "1", "--particles", "32768", "--no-cpu-baseline"]
-    out2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
-                           "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=600)
+    out2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"] + common, env=env,
+                          capture_output=True, text=True, timeout=600)
     assert out2.returncode == 0, out2.stderr[-2000:]
     line2 = json.loads([ln for ln in out2.stdout.splitlines() if ln.startswith("{")][-1])
     out1 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1"] + common, capture_output=True,
                           text=True, timeout=600)
     assert out1.returncode == 0, out1.stderr[-2000:]
     line1 = json.loads([ln for ln in out1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len([ln for ln in out2.stdout.splitlines() if ln.strip()]) == 1          # stdout = the ONE JSON line
     assert line2["n_gpus"] == 2 and "HOST-STAGED" in line2["config"]["exchange"]
+    assert line2["config"]["rccl_ranks_seen"] == 0                                   # no communicator in this rehearsal
     for key in ("etot_first", "etot_last"):
         a, b = line2["energy_check"][key], line1["energy_check"][key]
         assert abs(a - b) <= 1e-11 * abs(b), (key, a, b)
