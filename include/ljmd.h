@@ -41,7 +41,8 @@ typedef enum ljmd_status {
     LJMD_ERR_INVALID_ARG = -1, /* a guard of md_types.f90:143-161 / lj_potential_energy.f90:77-82 failed */
     LJMD_ERR_NO_DEVICE = -2,   /* no HIP device / device code cannot run */
     LJMD_ERR_HIP = -3,         /* a HIP runtime call failed */
-    LJMD_ERR_STATE = -4,       /* call sequence error (e.g. step before set_state) */
+    LJMD_ERR_STATE = -4,       /* call sequence error (e.g. step before set_state), or a handle poisoned by a
+                                  batch of steps that failed half-way: ljmd_set_state makes it usable again */
     LJMD_ERR_ALLOC = -5
 } ljmd_status;
 
@@ -82,6 +83,24 @@ const char *ljmd_last_error(const ljmd_t *h);
 int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc,
                 int32_t precision_mode, int32_t device, int32_t rank, int32_t n_ranks);
 void ljmd_destroy(ljmd_t *h);
+
+/*
+ * ONE host process, n_gpus devices (the thin Fortran driver's way to BASELINE config 4: N = 1 048 576 sharded
+ * over the 8 GPUs of a node; the reference's caller loop md_simulation_program.f90:300-391 stays as it is).
+ * The returned handle is used with the SAME entry points as a single-GPU handle -- ljmd_set_state / set_accel /
+ * set_unwrapped / get_state, ljmd_compute_forces, ljmd_verlet_steps, ljmd_enqueue_steps / collect_steps,
+ * ljmd_snapshot_begin / end, ljmd_kinetic_energy, ljmd_synchronize, ljmd_profile_*, ljmd_destroy -- with global
+ * (length-n) arrays; inside, rank g = one engine on devices[g] (NULL = devices 0 .. n_gpus-1) integrating particles
+ * [g n/n_gpus, (g+1) n/n_gpus), and per step one all-gather of the position blocks and (Newton-3) one
+ * reduce-scatter of the partial accelerations, stream-ordered with no host synchronisation: RCCL over xGMI
+ * (ncclCommInitAll; the collectives of all ranks grouped from the one host thread), or peer-to-peer copies +
+ * a rank-ordered sum when LJMD_MULTI_EXCHANGE=copy or a device is listed more than once (RCCL refuses two ranks
+ * on one device; this is how several ranks are rehearsed on one card).  The split-phase functions below
+ * (ljmd_step_begin ...) are for the one-process-per-GPU form and return LJMD_ERR_STATE on such a handle.
+ * n must be divisible by n_gpus.
+ */
+int ljmd_create_multi(ljmd_t **out, int32_t n, double box_length, double dt, double rc,
+                      int32_t precision_mode, int32_t n_gpus, const int32_t *devices);
 
 /* ---- state transfer ------------------------------------------------------ */
 
@@ -177,7 +196,10 @@ int ljmd_verlet_step(int32_t n, double box_length, double dt, double rc,
  */
 int ljmd_rdf_histogram(int32_t n, const double *x, const double *y, const double *z, double box_length,
                        int32_t nbins, double rmax, uint64_t *hist);
-/* Frees the cached engines of the stateless entry points. */
+/* The stateless entry points keep one cached engine (device LJMD_DEVICE, default 0).  ljmd_verlet_step
+ * remembers the nine arrays it handed back; when the next call passes the same bytes again (the reference's
+ * loop only reads them between steps) the resident state is stepped directly -- no upload, no spatial re-sort,
+ * only the download (LJMD_STATELESS_FASTPATH=0 disables the check).  This frees the cached engine. */
 void ljmd_stateless_reset(void);
 
 /* ---- multi-GPU split-phase API (one process per GPU) -------- */

@@ -47,6 +47,8 @@ PROTOTYPES = {
     "ljmd_last_error": (C.c_char_p, [C.c_void_p]),
     "ljmd_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.c_double, C.c_double,
                               C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "ljmd_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                    C.c_int32, c_int32_p]),
     "ljmd_destroy": (None, [C.c_void_p]),
     "ljmd_set_state": (C.c_int, [C.c_void_p] + [c_double_p] * 6),
     "ljmd_set_accel": (C.c_int, [C.c_void_p] + [c_double_p] * 3),

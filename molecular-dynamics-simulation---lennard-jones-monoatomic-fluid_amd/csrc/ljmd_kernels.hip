@@ -19,8 +19,9 @@
 namespace ljmdk {
 
 // ---------------------------------------------------------------------------
-// wave / block reductions with a FIXED combination order (bitwise reproducible
-// run to run: no atomics anywhere in this file).
+// wave / block reductions with a FIXED combination order: every floating-point sum in this file
+// is bitwise reproducible run to run.  The only atomics are integer ones that cannot change a result:
+// the blocks-done ticket of kick_finalize_kernel and the integer histogram of rdf_histogram_kernel.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
 {

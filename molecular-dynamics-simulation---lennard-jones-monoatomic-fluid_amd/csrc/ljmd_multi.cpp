@@ -1,0 +1,416 @@
+// ljmd_multi.cpp -- ONE host process driving G MI355X devices (ljmd_create_multi): what a thin Fortran driver
+// needs to run BASELINE config 4 (N = 1 048 576 sharded over the 8 GPUs of a node) without a process launcher.
+//
+// The parent handle owns one ordinary engine per device (rank g of G: it integrates particles [g S, (g+1) S)
+// and evaluates those rows of the pair matrix) and issues the two data-path exchanges itself,
+// stream-ordered, with no host synchronisation inside a batch of steps:
+//   positions   drift kernels of all ranks | all-gather of the 3P-double position blocks | pair kernels
+//   forces      (Newton-3) pair kernels + slab reductions | reduce-scatter of fpart[G][3][P] | kick kernels
+// exchange = RCCL (default for distinct devices): ncclCommInitAll communicators, each collective issued for all
+//   ranks inside one ncclGroupStart/End from this one thread, on the engines' own streams;
+// exchange = copy (LJMD_MULTI_EXCHANGE=copy, and always when a device is listed twice -- RCCL refuses two ranks
+//   on one device, so this is also how several ranks are rehearsed on one card): every rank PULLS the blocks it
+//   needs with peer-to-peer hipMemcpyAsync on its own stream behind the owner's event and adds the G force
+//   blocks in rank order (launch_sum_blocks): explicit, run-to-run deterministic summation order.
+// The per-step scalar records stay on the devices; they are read back once per batch and combined on the host
+// in rank order (combine_one), exactly as the multi-process path does.
+#include "ljmd_multi.h"
+
+using namespace ljmdk;
+using namespace ljmdh;
+
+struct ljmd_multi {
+    int G = 0;
+    std::vector<ljmd_t *> eng;
+    std::vector<int> dev;
+    bool rccl = false;
+    std::vector<ncclComm_t> comm;
+    std::vector<hipEvent_t> ev_pos, ev_force;     // copy exchange: "rank g's block is ready"
+    std::vector<double> recs;                     // [G][kPartialStride] scratch of one step
+};
+
+namespace ljmdm {
+
+namespace {
+
+#define LJMD_TRY(expr)                      \
+    do {                                    \
+        const int rc__ = (expr);            \
+        if (rc__ != LJMD_OK) return rc__;   \
+    } while (0)
+
+// a child's error text becomes the parent's
+int child_failed(ljmd_t *h, const ljmd_t *c, int code)
+{
+    return fail(h, code, "rank %d (device %d): %s", c->rank, c->device, c->err.c_str());
+}
+
+#define LJMD_CHILD(h, c, expr)                                   \
+    do {                                                         \
+        const int rc__ = (expr);                                 \
+        if (rc__ != LJMD_OK) return child_failed((h), (c), rc__); \
+    } while (0)
+
+int exchange_positions(ljmd_t *h)
+{
+    ljmd_multi *m = h->multi;
+    if (m->G == 1 && !m->eng[0]->force_collectives) return LJMD_OK;
+    if (m->rccl) {
+        ncclResult_t r = ncclGroupStart();
+        for (int g = 0; g < m->G && r == ncclSuccess; ++g) {
+            ljmd_t *e = m->eng[g];
+            r = ncclAllGather(own_block(e), e->d_pos, 3 * (size_t)e->P, ncclDouble, m->comm[g], e->stream);
+        }
+        const ncclResult_t end = ncclGroupEnd();
+        if (r == ncclSuccess) r = end;
+        if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "multi-device all-gather failed: %s", ncclGetErrorString(r));
+        return LJMD_OK;
+    }
+    for (int g = 0; g < m->G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_HIP(h, hipEventRecord(m->ev_pos[g], m->eng[g]->stream));
+    }
+    for (int d = 0; d < m->G; ++d) {
+        ljmd_t *dst = m->eng[d];
+        LJMD_HIP(h, hipSetDevice(m->dev[d]));
+        const size_t blk = 3 * (size_t)dst->P;
+        for (int g = 0; g < m->G; ++g) {
+            if (g == d) continue;
+            LJMD_HIP(h, hipStreamWaitEvent(dst->stream, m->ev_pos[g], 0));
+            LJMD_HIP(h, hipMemcpyAsync(dst->d_pos + (size_t)g * blk, own_block(m->eng[g]), blk * sizeof(double),
+                                       hipMemcpyDeviceToDevice, dst->stream));
+        }
+    }
+    return LJMD_OK;
+}
+
+int exchange_forces(ljmd_t *h)
+{
+    ljmd_multi *m = h->multi;
+    if (!needs_force_exchange(m->eng[0])) return LJMD_OK;     // gather kernels: every rank already has its rows
+    if (m->rccl) {
+        ncclResult_t r = ncclGroupStart();
+        for (int g = 0; g < m->G && r == ncclSuccess; ++g) {
+            ljmd_t *e = m->eng[g];
+            r = ncclReduceScatter(e->d_fpart, e->d_frecv, 3 * (size_t)e->P, ncclDouble, ncclSum, m->comm[g], e->stream);
+        }
+        const ncclResult_t end = ncclGroupEnd();
+        if (r == ncclSuccess) r = end;
+        if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "multi-device reduce-scatter failed: %s", ncclGetErrorString(r));
+        return LJMD_OK;
+    }
+    for (int g = 0; g < m->G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_HIP(h, hipEventRecord(m->ev_force[g], m->eng[g]->stream));
+    }
+    for (int d = 0; d < m->G; ++d) {
+        ljmd_t *dst = m->eng[d];
+        LJMD_HIP(h, hipSetDevice(m->dev[d]));
+        const size_t blk = 3 * (size_t)dst->P;
+        for (int g = 0; g < m->G; ++g) {
+            if (g != d) LJMD_HIP(h, hipStreamWaitEvent(dst->stream, m->ev_force[g], 0));
+            LJMD_HIP(h, hipMemcpyAsync(dst->d_fall + (size_t)g * blk, m->eng[g]->d_fpart + (size_t)d * blk,
+                                       blk * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+        }
+        LJMD_HIP(h, launch_sum_blocks(dst->d_fall, dst->d_frecv, m->G, (int)blk, dst->stream));   // rank order
+    }
+    return LJMD_OK;
+}
+
+// forces of all ranks on the positions in the exchange buffers (already exchanged) + optional second half-kick
+int enqueue_forces_all(ljmd_t *h, bool kick, const std::vector<EventSet *> &q)
+{
+    ljmd_multi *m = h->multi;
+    for (int g = 0; g < m->G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_CHILD(h, m->eng[g], enqueue_pair_forces(m->eng[g], q[g]));
+    }
+    LJMD_TRY(exchange_forces(h));
+    for (int g = 0; g < m->G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_CHILD(h, m->eng[g], enqueue_kick(m->eng[g], kick, q[g]));
+    }
+    return LJMD_OK;
+}
+
+int enqueue_one_step(ljmd_t *h)
+{
+    ljmd_multi *m = h->multi;
+    std::vector<EventSet *> q(m->G, nullptr);
+    for (int g = 0; g < m->G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        q[g] = next_events(m->eng[g]);
+        LJMD_CHILD(h, m->eng[g], enqueue_drift(m->eng[g], q[g]));
+    }
+    LJMD_TRY(exchange_positions(h));
+    return enqueue_forces_all(h, true, q);
+}
+
+// reads the last `count` records of every rank and combines them step by step in rank order
+int collect(ljmd_t *h, int count, double *epot, double *ekin, double *d_epot, double *dd_epot)
+{
+    ljmd_multi *m = h->multi;
+    for (int g = 0; g < m->G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_CHILD(h, m->eng[g], fetch_ring(m->eng[g], (unsigned)count));
+    }
+    m->recs.resize((size_t)m->G * kPartialStride);
+    for (int s = 0; s < count; ++s) {
+        for (int g = 0; g < m->G; ++g)
+            std::memcpy(&m->recs[(size_t)g * kPartialStride], m->eng[g]->h_ring + (size_t)s * kPartialStride,
+                        kPartialStride * sizeof(double));
+        combine_one(h, m->recs.data(), m->G, epot ? epot + s : nullptr, ekin ? ekin + s : nullptr,
+                    d_epot ? d_epot + s : nullptr, dd_epot ? dd_epot + s : nullptr);
+    }
+    return LJMD_OK;
+}
+
+unsigned pending(const ljmd_t *h) { const ljmd_t *e = h->multi->eng[0]; return e->ring_issued - e->ring_consumed; }
+
+}  // namespace
+
+int create(ljmd_t **out, int32_t n, double box_length, double dt, double rc, int32_t precision_mode,
+           int32_t n_gpus, const int32_t *devices)
+{
+    if (!out) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create_multi: out is NULL");
+    *out = nullptr;
+    if (n_gpus < 1 || n_gpus > 64) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create_multi: n_gpus = %d", n_gpus);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LJMD_ERR_NO_DEVICE, "ljmd_create_multi: no HIP device available (this library has no CPU path)");
+    ljmd_t *h = new (std::nothrow) ljmd;
+    ljmd_multi *m = new (std::nothrow) ljmd_multi;
+    if (!h || !m) {
+        delete h;
+        delete m;
+        return fail(nullptr, LJMD_ERR_ALLOC, "ljmd_create_multi: out of host memory");
+    }
+    h->multi = m;
+    h->device = -1;
+    m->G = n_gpus;
+    bool distinct = true;
+    for (int g = 0; g < n_gpus; ++g) {
+        const int d = devices ? devices[g] : g;
+        if (d < 0 || d >= ndev) {
+            destroy(h);
+            return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_create_multi: device %d for rank %d, but %d device(s) visible", d,
+                        g, ndev);
+        }
+        for (int k : m->dev) distinct = distinct && k != d;
+        m->dev.push_back(d);
+    }
+    const char *xm = std::getenv("LJMD_MULTI_EXCHANGE");
+    m->rccl = distinct && !(xm && std::strcmp(xm, "copy") == 0);
+    for (int g = 0; g < n_gpus; ++g) {
+        ljmd_t *e = nullptr;
+        const int rc_ = ljmd_create(&e, n, box_length, dt, rc, precision_mode, m->dev[g], g, n_gpus);
+        if (rc_ != LJMD_OK) {
+            destroy(h);                                   // g_last_error holds the child's message
+            return rc_;
+        }
+        e->external_force_exchange = true;                // both exchanges are issued here, for all ranks at once
+        m->eng.push_back(e);
+    }
+    // the parent carries the parameters the scalar combination needs (tail constants) and what callers query
+    const ljmd_t *e0 = m->eng[0];
+    h->n = n; h->G = n_gpus; h->S = e0->S; h->P = e0->P; h->mode = precision_mode;
+    h->L = e0->L; h->invL = e0->invL; h->volume = e0->volume; h->rc = e0->rc; h->rc2 = e0->rc2;
+    h->dt = e0->dt; h->dt_half = e0->dt_half; h->dt_sq_half = e0->dt_sq_half;
+    h->tail_e = e0->tail_e; h->tail_d = e0->tail_d; h->tail_dd = e0->tail_dd;
+    auto body = [&]() -> int {
+        if (m->rccl) {
+            m->comm.assign(n_gpus, nullptr);
+            const ncclResult_t r = ncclCommInitAll(m->comm.data(), n_gpus, m->dev.data());
+            if (r != ncclSuccess) {
+                m->comm.clear();
+                return fail(h, LJMD_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", n_gpus, ncclGetErrorString(r));
+            }
+            return LJMD_OK;
+        }
+        m->ev_pos.assign(n_gpus, nullptr);
+        m->ev_force.assign(n_gpus, nullptr);
+        for (int g = 0; g < n_gpus; ++g) {
+            LJMD_HIP(h, hipSetDevice(m->dev[g]));
+            LJMD_HIP(h, hipEventCreateWithFlags(&m->ev_pos[g], hipEventDisableTiming));
+            LJMD_HIP(h, hipEventCreateWithFlags(&m->ev_force[g], hipEventDisableTiming));
+            for (int k = 0; k < n_gpus; ++k)
+                if (m->dev[k] != m->dev[g]) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(m->dev[k], 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                        return fail(h, LJMD_ERR_HIP, "peer access %d -> %d unavailable: %s", m->dev[g], m->dev[k],
+                                    hipGetErrorString(pe));
+                    (void)hipGetLastError();
+                }
+            ljmd_t *e = m->eng[g];
+            if (needs_force_exchange(e) && !e->d_fall)
+                LJMD_HIP(h, hipMalloc(&e->d_fall, 3 * (size_t)e->P * sizeof(double) * n_gpus));
+        }
+        return LJMD_OK;
+    };
+    const int rc_ = body();
+    if (rc_ != LJMD_OK) {
+        g_last_error = h->err;
+        destroy(h);
+        return rc_;
+    }
+    *out = h;
+    return LJMD_OK;
+}
+
+void destroy(ljmd_t *h)
+{
+    if (!h) return;
+    ljmd_multi *m = h->multi;
+    if (m) {
+        for (size_t g = 0; g < m->eng.size(); ++g) {
+            (void)hipSetDevice(m->dev[g]);
+            if (m->eng[g]->stream) (void)hipStreamSynchronize(m->eng[g]->stream);
+        }
+        for (ncclComm_t c : m->comm)
+            if (c) (void)ncclCommDestroy(c);
+        for (size_t g = 0; g < m->ev_pos.size(); ++g) {
+            (void)hipSetDevice(m->dev[g]);
+            if (m->ev_pos[g]) (void)hipEventDestroy(m->ev_pos[g]);
+            if (m->ev_force[g]) (void)hipEventDestroy(m->ev_force[g]);
+        }
+        for (ljmd_t *e : m->eng) release(e);
+        delete m;
+    }
+    delete h;
+}
+
+int set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz, const double *vx, const double *vy,
+              const double *vz)
+{
+    ljmd_multi *m = h->multi;
+    for (ljmd_t *e : m->eng) LJMD_CHILD(h, e, ljmd_set_state(e, rx, ry, rz, vx, vy, vz));
+    h->have_state = true;
+    h->have_accel = false;
+    h->poisoned = false;
+    return exchange_positions(h);      // every rank re-ordered its own block: share the new slot order
+}
+
+int set_accel(ljmd_t *h, const double *ax, const double *ay, const double *az)
+{
+    for (ljmd_t *e : h->multi->eng) LJMD_CHILD(h, e, ljmd_set_accel(e, ax, ay, az));
+    h->have_accel = true;
+    return LJMD_OK;
+}
+
+int set_unwrapped(ljmd_t *h, const double *ux, const double *uy, const double *uz)
+{
+    for (ljmd_t *e : h->multi->eng) LJMD_CHILD(h, e, ljmd_set_unwrapped(e, ux, uy, uz));
+    return LJMD_OK;
+}
+
+int get_state(ljmd_t *h, double *const p[12])
+{
+    for (ljmd_t *e : h->multi->eng) {
+        double *q[12];
+        for (int k = 0; k < 12; ++k) q[k] = p[k] ? p[k] + (size_t)e->rank * e->S : nullptr;
+        LJMD_CHILD(h, e, ljmd_get_state(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]));
+    }
+    return LJMD_OK;
+}
+
+int compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot)
+{
+    ljmd_multi *m = h->multi;
+    const std::vector<EventSet *> q(m->G, nullptr);
+    LJMD_TRY(enqueue_forces_all(h, false, q));
+    h->have_accel = true;
+    return collect(h, 1, epot, nullptr, d_epot, dd_epot);
+}
+
+int enqueue_steps(ljmd_t *h, int32_t nsteps)
+{
+    if (pending(h) + (unsigned)nsteps > kRingCap)
+        return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: %u + %d pending steps exceed LJMD_MAX_PENDING_STEPS", pending(h),
+                    nsteps);
+    for (int s = 0; s < nsteps; ++s) {
+        const int rc_ = enqueue_one_step(h);
+        if (rc_ != LJMD_OK) {
+            h->poisoned = true;        // some ranks are a phase ahead of the others
+            return rc_;
+        }
+    }
+    return LJMD_OK;
+}
+
+int collect_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, double *d_epot, double *dd_epot)
+{
+    return collect(h, nsteps, epot, ekin, d_epot, dd_epot);
+}
+
+int snapshot_begin(ljmd_t *h)
+{
+    for (ljmd_t *e : h->multi->eng) LJMD_CHILD(h, e, ljmd_snapshot_begin(e));
+    return LJMD_OK;
+}
+
+int snapshot_end(ljmd_t *h, double *const p[12])
+{
+    for (ljmd_t *e : h->multi->eng) {
+        double *q[12];
+        for (int k = 0; k < 12; ++k) q[k] = p[k] ? p[k] + (size_t)e->rank * e->S : nullptr;
+        LJMD_CHILD(h, e, ljmd_snapshot_end(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]));
+    }
+    return LJMD_OK;
+}
+
+int kinetic_energy(ljmd_t *h, double *ekin)
+{
+    double total = 0.0;
+    for (ljmd_t *e : h->multi->eng) {      // rank order
+        double part = 0.0;
+        LJMD_CHILD(h, e, ljmd_kinetic_energy(e, &part));
+        total += part;
+    }
+    *ekin = total;
+    return LJMD_OK;
+}
+
+int synchronize(ljmd_t *h)
+{
+    for (ljmd_t *e : h->multi->eng) LJMD_CHILD(h, e, ljmd_synchronize(e));
+    return LJMD_OK;
+}
+
+int profile_enable(ljmd_t *h, int32_t on)
+{
+    for (ljmd_t *e : h->multi->eng) LJMD_CHILD(h, e, ljmd_profile_enable(e, on));
+    return LJMD_OK;
+}
+
+int profile_read_ex(ljmd_t *h, double *ms_avg, double *ms_min, int32_t *launches)
+{
+    // the slowest rank bounds the step: per interval the maximum over the ranks
+    double avg[4] = {0, 0, 0, 0}, mn[4] = {0, 0, 0, 0};
+    int32_t cnt = 0;
+    for (ljmd_t *e : h->multi->eng) {
+        double a[4], b[4];
+        int32_t c = 0;
+        LJMD_CHILD(h, e, ljmd_profile_read_ex(e, a, b, &c));
+        for (int k = 0; k < 4; ++k) {
+            avg[k] = std::max(avg[k], a[k]);
+            mn[k] = std::max(mn[k], b[k]);
+        }
+        cnt = std::max(cnt, c);
+    }
+    if (ms_avg) std::memcpy(ms_avg, avg, sizeof avg);
+    if (ms_min) std::memcpy(ms_min, mn, sizeof mn);
+    if (launches) *launches = cnt;
+    return LJMD_OK;
+}
+
+const char *pair_kernel_name(const ljmd_t *h) { return ljmd_pair_kernel_name(h->multi->eng[0]); }
+
+int32_t comm_size(const ljmd_t *h)
+{
+    const ljmd_multi *m = h->multi;
+    if (!m->rccl || m->comm.empty() || !m->comm[0]) return 0;
+    int count = 0;
+    return ncclCommCount(m->comm[0], &count) == ncclSuccess ? count : 0;
+}
+
+}  // namespace ljmdm

@@ -15,7 +15,7 @@ module ljmd_c_api
   private
 
   public :: ljmd_compute_lj_potential_energy, ljmd_verlet_step, ljmd_stateless_reset
-  public :: ljmd_create, ljmd_destroy, ljmd_set_state, ljmd_set_accel, ljmd_set_unwrapped
+  public :: ljmd_create, ljmd_create_multi, ljmd_destroy, ljmd_set_state, ljmd_set_accel, ljmd_set_unwrapped
   public :: ljmd_get_state, ljmd_compute_forces, ljmd_verlet_steps, ljmd_kinetic_energy
   public :: ljmd_last_error, ljmd_device_count, ljmd_profile_enable, ljmd_profile_read
   public :: ljmd_enqueue_steps, ljmd_collect_steps, ljmd_snapshot_begin, ljmd_snapshot_end
@@ -55,6 +55,17 @@ module ljmd_c_api
       type(c_ptr), intent(out) :: handle
       integer(c_int32_t), value :: n, precision_mode, device, rank, n_ranks
       real(c_double), value :: box_length, dt, rc
+      integer(c_int) :: status
+    end function
+
+    ! one process, n_gpus devices (devices = c_null_ptr: 0 .. n_gpus-1); same entry points afterwards
+    function ljmd_create_multi(handle, n, box_length, dt, rc, precision_mode, n_gpus, devices) &
+        bind(C, name="ljmd_create_multi") result(status)
+      import :: c_int, c_int32_t, c_double, c_ptr
+      type(c_ptr), intent(out) :: handle
+      integer(c_int32_t), value :: n, precision_mode, n_gpus
+      real(c_double), value :: box_length, dt, rc
+      type(c_ptr), value :: devices
       integer(c_int) :: status
     end function
 

@@ -12,7 +12,10 @@
 ! next sampling step without touching the host; r, ru, v, a come back only when a snapshot is
 ! written) and the per-step unwrapped-coordinate update (:339-353) happens inside the drift
 ! kernel; snapshots leave the GPU through ljmd_snapshot_begin/end while the next steps already run.
-! Environment: LJMD_DEVICE (default 0), LJMD_ASYNC_IO (default 1).
+! Environment: LJMD_DEVICE (default 0), LJMD_ASYNC_IO (default 1), LJMD_GPUS (default 1; > 1: this one process
+! drives that many devices -- ljmd_create_multi, particles sharded by index range, RCCL all-gather of positions and
+! reduce-scatter of forces per step inside the library -- e.g. BASELINE config 4 with LJMD_GPUS=8; LJMD_DEVICES, a
+! comma-separated device list of that length, overrides 0..LJMD_GPUS-1).
 !==============================================================================
 program md_simulation_gpu
   use, intrinsic :: iso_c_binding
@@ -33,7 +36,9 @@ program md_simulation_gpu
   real(kind=dp_kind) :: epot, ekin, etot, d_epot, dd_epot, time, temp_inst, press_inst, npd
   integer(kind=int_kind) :: step, count, k, num_samples
   logical :: sample_now, async_io
-  integer :: iu_rva, iu_out, ios, device
+  integer :: iu_rva, iu_out, ios, device, n_gpus
+  integer(c_int32_t), allocatable, target :: device_list(:)
+  character(len=256) :: env_list
   integer(kind=8) :: c0, c1, crate
   type(c_ptr) :: engine
   type(run_statistics) :: stats
@@ -52,9 +57,22 @@ program md_simulation_gpu
   call get_environment_variable('LJMD_ASYNC_IO', env, status=ios)
   if (ios == 0 .and. len_trim(env) > 0) async_io = trim(env) /= '0'
 
-  call ljmd_check(ljmd_create(engine, params%n, params%box_length, params%dt, params%rc, &
-                              LJMD_PRECISION_FP64, int(device, c_int32_t), 0_c_int32_t, 1_c_int32_t), &
-                  c_null_ptr, 'ljmd_create')
+  n_gpus = 1
+  call get_environment_variable('LJMD_GPUS', env, status=ios)
+  if (ios == 0 .and. len_trim(env) > 0) read(env, *) n_gpus
+  if (n_gpus > 1) then
+    allocate(device_list(n_gpus))
+    device_list = [(int(k - 1, c_int32_t), k = 1, n_gpus)]
+    call get_environment_variable('LJMD_DEVICES', env_list, status=ios)
+    if (ios == 0 .and. len_trim(env_list) > 0) read(env_list, *) device_list
+    call ljmd_check(ljmd_create_multi(engine, params%n, params%box_length, params%dt, params%rc, &
+                                      LJMD_PRECISION_FP64, int(n_gpus, c_int32_t), c_loc(device_list)), &
+                    c_null_ptr, 'ljmd_create_multi')
+  else
+    call ljmd_check(ljmd_create(engine, params%n, params%box_length, params%dt, params%rc, &
+                                LJMD_PRECISION_FP64, int(device, c_int32_t), 0_c_int32_t, 1_c_int32_t), &
+                    c_null_ptr, 'ljmd_create')
+  end if
   ! H2D; the library sets ru <- r (md_simulation_program.f90:229-231)
   call ljmd_check(ljmd_set_state(engine, c_loc(state%rx), c_loc(state%ry), c_loc(state%rz), &
                                  c_loc(state%vx), c_loc(state%vy), c_loc(state%vz)), engine, 'ljmd_set_state')

@@ -80,6 +80,11 @@ def verlet_step(params: SimParams, state: SimState):
     return tuple(o.value for o in out)
 
 
+def stateless_reset() -> None:
+    """Frees the cached engine behind compute_lj_potential_energy / verlet_step (ljmd_stateless_reset)."""
+    _lib.load().ljmd_stateless_reset()
+
+
 def minimum_image(dx: float, box_length: float, inv_box_length: float) -> float:
     """geometry_pbc.f90:80-88 (dnint = round half away from zero); host helper."""
     t = dx * inv_box_length
@@ -88,18 +93,26 @@ def minimum_image(dx: float, box_length: float, inv_box_length: float) -> float:
 
 
 class Engine:
-    """HBM-resident simulation on one GPU (or one shard of a multi-GPU run)."""
+    """HBM-resident simulation on one GPU (or one shard of a multi-GPU run).
+    devices=[d0, d1, ...]: ONE process driving several devices (ljmd_create_multi): rank g of len(devices) runs on
+    devices[g]; the handle then takes and returns global arrays like a single-GPU one."""
 
     def __init__(self, params: SimParams, device: int = 0, rank: int = 0, n_ranks: int = 1,
-                 precision_mode: int = _lib.PRECISION_FP64):
+                 precision_mode: int = _lib.PRECISION_FP64, devices=None):
         self._lib = _lib.load()
         self.params = params
         self.rank, self.n_ranks = rank, n_ranks
         h = C.c_void_p()
-        _lib.check(self._lib.ljmd_create(C.byref(h), params.n, params.box_length, params.dt, params.rc,
-                                         precision_mode, device, rank, n_ranks))
+        if devices is not None:
+            devs = (C.c_int32 * len(devices))(*devices)
+            _lib.check(self._lib.ljmd_create_multi(C.byref(h), params.n, params.box_length, params.dt, params.rc,
+                                                   precision_mode, len(devices), devs))
+            self.rank, self.n_ranks = 0, 1          # global arrays in, global arrays out
+        else:
+            _lib.check(self._lib.ljmd_create(C.byref(h), params.n, params.box_length, params.dt, params.rc,
+                                             precision_mode, device, rank, n_ranks))
         self._h = h
-        self.shard = params.n // n_ranks
+        self.shard = params.n // self.n_ranks
 
     # -- lifecycle ---------------------------------------------------------
     def close(self) -> None:

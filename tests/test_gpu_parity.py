@@ -758,3 +758,65 @@ def test_fused_launches_are_bitwise_equal_to_the_separate_kernels(n, monkeypatch
             out.append((e0, sc, e1, np.stack([np.stack(st[k]) for k in ("r", "ru", "v", "a")])))
     assert out[0][0] == out[1][0] and out[0][2] == out[1][2]
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3])
+
+
+def test_failed_batch_poisons_the_handle_until_set_state(monkeypatch):
+    """A failure in the middle of a batch of steps (here injected: the force phase of the 4th evaluation fails
+    behind an already enqueued drift) leaves no trajectory point on the device: every stepping entry point then
+    returns LJMD_ERR_STATE until ljmd_set_state, after which the handle behaves like a fresh one (bitwise)."""
+    p, r, v = synthetic.make_config(4096, seed=12)
+    with Engine(p) as ref:
+        ref.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e_ref = ref.compute_forces()
+        sc_ref = np.stack(ref.verlet_steps(30), axis=1)
+    monkeypatch.setenv("LJMD_INJECT_FAILURE_AT_STEP", "3")     # evaluations: t = 0 force call, steps 1, 2, [3]
+    with Engine(p) as eng:
+        monkeypatch.delenv("LJMD_INJECT_FAILURE_AT_STEP")
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert eng.compute_forces() == e_ref
+        with pytest.raises(ljmd_amd.LjmdError, match="injected failure"):
+            eng.verlet_steps(10)
+        for call in (lambda: eng.verlet_steps(1), lambda: eng.enqueue_steps(1), lambda: eng.collect_steps(1),
+                     eng.compute_forces):
+            with pytest.raises(ljmd_amd.LjmdError, match="poisoned"):
+                call()
+        eng.get_state()                                        # reading the (meaningless) state is still allowed
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])      # recovery
+        assert eng.compute_forces() == e_ref
+        assert np.array_equal(np.stack(eng.verlet_steps(30), axis=1), sc_ref)
+
+
+def test_stateless_verlet_step_resident_fast_path(monkeypatch):
+    """ljmd_verlet_step called in a loop the way the reference's own program does (md_simulation_program.f90:
+    303-353 only READS the arrays between steps): from the second call on the arrays are the ones the library handed
+    back, so it steps the resident state -- no upload, no re-sort.  Same trajectory as the strict path
+    (LJMD_STATELESS_FASTPATH=0) within rounding (the slot order, hence the summation order, differs), and any
+    change of any array by the caller falls back to the strict path."""
+    import time
+    from ljmd_amd import physics
+    n, steps = 32768, 12
+    p, r, v = synthetic.make_config(n, seed=4)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LJMD_STATELESS_FASTPATH", mode)
+        physics.stateless_reset()
+        st = init_state(p)
+        st.rx[:], st.ry[:], st.rz[:] = r
+        st.vx[:], st.vy[:], st.vz[:] = v
+        physics.compute_lj_potential_energy(p, st)
+        sc = []
+        t0 = time.perf_counter()
+        for k in range(steps):
+            if k == 7:
+                st.vx[5] += 0.0                                # same bytes: still the fast path
+            if k == 9:
+                st.vx[5] = np.nextafter(st.vx[5], 1.0)         # the caller touched the state: strict path, exact effect
+            sc.append(physics.verlet_step(p, st))
+        res[mode] = (np.array(sc), np.stack([st.rx, st.vx, st.ax]).copy(), time.perf_counter() - t0)
+    physics.stateless_reset()
+    fast, strict = res["1"], res["0"]
+    assert np.max(np.abs(fast[0] - strict[0]) / np.abs(strict[0])) < 1e-11
+    assert np.abs(fast[1] - strict[1]).max() < 1e-9
+    print(f"stateless verlet_step loop, n = {n}: resident fast path {fast[2] / steps * 1e3:.2f} ms/call, "
+          f"strict {strict[2] / steps * 1e3:.2f} ms/call")
+    assert fast[2] < strict[2]

@@ -210,3 +210,103 @@ def test_bench_two_processes_host_staged_exchange(tmp_path):
         a, b = line2["energy_check"][key], line1["energy_check"][key]
         assert abs(a - b) <= 1e-11 * abs(b), (key, a, b)
     assert line2["value"] > 0 and line2["roofline"]["kernel"] == "pair_n3_kernel"
+
+
+# ---- ONE process, several ranks: ljmd_create_multi -----------------------------------------------------------
+
+@pytest.mark.parametrize("n,G", [(16384, 2), (16384, 4), (8192, 8), (3000, 3)])
+def test_multi_device_handle_emulated_ranks(n, G, monkeypatch):
+    """ljmd_create_multi with the SAME device listed G times: G rank engines on this box's one card, the library's
+    own copy exchange (peer pulls behind events + rank-ordered sum; RCCL refuses two ranks on one device) -- the
+    whole single-process multi-device control flow of the thin Fortran driver (LJMD_GPUS), with global arrays in
+    and out.  Against the single engine: same bounds as the emulated-ranks test above; against a re-run: bitwise."""
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+    p, r, v = synthetic.make_config(n, seed=5)
+    nsteps = 25                                            # crosses a re-sort (every 20 steps)
+    with Engine(p) as one:
+        one.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e0 = one.compute_forces()
+        k0 = one.kinetic_energy()
+        ref = np.stack(one.verlet_steps(nsteps), axis=1)
+        ref_state = one.get_state()
+    runs = []
+    for _rep in range(2):
+        with Engine(p, devices=[0] * G) as multi:
+            assert multi.comm_size() == 0                  # copy exchange: no communicator
+            assert multi.pair_kernel_name() == "pair_rows_generic_kernel"    # nothing set yet
+            multi.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            assert multi.pair_kernel_name() == "pair_n3_kernel"
+            m0 = multi.compute_forces()
+            assert np.allclose(m0, e0, rtol=1e-13, atol=0)
+            assert abs(multi.kinetic_energy() - k0) <= 1e-14 * k0
+            sc = np.stack(multi.verlet_steps(nsteps), axis=1)
+            st = multi.get_state()
+            with pytest.raises(ljmd_amd.LjmdError, match="multi-device"):
+                multi.step_begin()                         # split-phase API belongs to the one-process-per-GPU form
+            runs.append((m0, sc, st))
+    m0, sc, st = runs[0]
+    assert np.max(np.abs(sc - ref) / np.abs(ref)) < 1e-11
+    for key in ("r", "ru", "v", "a"):
+        mine, want = np.stack(st[key]), np.stack(ref_state[key])
+        assert np.abs(mine - want).max() < 1e-9 * max(np.abs(want).max(), 1.0), key
+    assert runs[1][0] == m0 and np.array_equal(runs[1][1], sc)                 # run-to-run: bitwise
+    for key in ("r", "ru", "v", "a"):
+        assert np.array_equal(np.stack(runs[1][2][key]), np.stack(st[key])), key
+
+
+def test_multi_device_handle_one_rank_equals_plain_engine_bitwise(monkeypatch):
+    """n_gpus = 1: RCCL communicator over one device (ncclCommInitAll), no exchange needed -- bit for bit the plain
+    engine, including the asynchronous production-loop entry points the Fortran driver uses."""
+    p, r, v = synthetic.make_config(16384, seed=9)
+    out = []
+    for devices in (None, [0]):
+        with Engine(p, devices=devices) as eng:
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            e0 = eng.compute_forces()
+            eng.enqueue_steps(12)
+            eng.snapshot_begin()
+            eng.enqueue_steps(10)                          # runs while the snapshot leaves the device
+            snap = eng.snapshot_end()
+            sc = np.stack(eng.collect_steps(10), axis=1)
+            out.append((e0, sc, snap, eng.get_state(), eng.comm_size()))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    for key in ("r", "ru", "v", "a"):
+        assert np.array_equal(np.stack(out[0][2][key]), np.stack(out[1][2][key])), key
+        assert np.array_equal(np.stack(out[0][3][key]), np.stack(out[1][3][key])), key
+    assert out[0][4] == 0 and out[1][4] == 1               # RCCL itself reports the 1-rank communicator
+
+
+def test_multi_device_handle_rccl_collectives_one_rank(monkeypatch):
+    """LJMD_FORCE_COLLECTIVES=1 on a 1-device multi handle: the grouped ncclAllGather / ncclReduceScatter calls of
+    the single-process path really run (1-rank communicator, all this box can host), trajectory bitwise unchanged."""
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+    p, r, v = synthetic.make_config(16384, seed=3)
+    with Engine(p) as ref:
+        ref.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e_ref = ref.compute_forces()
+        sc_ref = np.stack(ref.verlet_steps(25), axis=1)
+    monkeypatch.setenv("LJMD_FORCE_COLLECTIVES", "1")
+    with Engine(p, devices=[0]) as eng:
+        assert eng.comm_size() == 1
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert eng.compute_forces() == e_ref
+        assert np.array_equal(np.stack(eng.verlet_steps(25), axis=1), sc_ref)
+
+
+def test_sharded_form_at_bench_size_eight_ranks_one_force_call():
+    """The sharded decomposition at the size where it matters (n = 262144, G = 8: 128 row groups per rank, the
+    NG/2 tie rule, several offset slices per rank, fpart[G] blocks, rank-ordered force sum), one force call through
+    the multi-device handle on this one card against the single engine."""
+    n, G = 262144, 8
+    p, r, v = synthetic.make_config(n)
+    with Engine(p) as one:
+        one.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e1 = one.compute_forces()
+        a1 = np.stack(one.get_state(("a",))["a"])
+    with Engine(p, devices=[0] * G) as multi:
+        multi.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e8 = multi.compute_forces()
+        a8 = np.stack(multi.get_state(("a",))["a"])
+    assert np.allclose(e8, e1, rtol=1e-12, atol=0), (e8, e1)
+    assert np.abs(a8 - a1).max() <= 1e-12 * np.abs(a1).max()
+    assert np.abs(a8.sum(axis=1)).max() <= 1e-9 * np.abs(a1).max()             # Newton 3 across ranks
