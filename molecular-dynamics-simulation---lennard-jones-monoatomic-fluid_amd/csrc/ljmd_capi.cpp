@@ -471,6 +471,43 @@ void release(ljmd_t *h)
     delete h;
 }
 
+// HBM -> host of any of r, ru, v, a (dsts[3 w + k], NULL = skip) and of the last n_records scalar records, all
+// behind ONE stream synchronisation; the arrays are delivered in the caller's original particle order.
+int download_state(ljmd_t *h, double *const dsts[12], unsigned n_records)
+{
+    const size_t P = h->P;
+    const double *srcs[4] = {own_block(h), h->d_ru, h->d_v, h->d_a};
+    bool want[4];
+    for (int w = 0; w < 4; ++w) {
+        want[w] = dsts[3 * w] || dsts[3 * w + 1] || dsts[3 * w + 2];
+        if (want[w])
+            LJMD_HIP(h, hipMemcpyAsync(h->h_stage + (size_t)w * 3 * P, srcs[w], 3 * P * sizeof(double),
+                                       hipMemcpyDeviceToHost, h->stream));
+    }
+    if (h->perm_dirty)
+        LJMD_HIP(h, hipMemcpyAsync(h->h_perm.data(), h->d_perm, P * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (n_records > 0) {
+        const int rc_ = fetch_ring(h, n_records);      // synchronises the stream
+        if (rc_ != LJMD_OK) return rc_;
+    } else {
+        LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    h->perm_dirty = false;
+    for (int w = 0; w < 4; ++w) {
+        if (!want[w]) continue;
+        for (int k = 0; k < 3; ++k) {
+            double *dst = dsts[3 * w + k];
+            if (!dst) continue;
+            const double *st = h->h_stage + ((size_t)w * 3 + k) * P;
+            for (int i = 0; i < h->P; ++i) {
+                const int o = h->h_perm[i];
+                if (o < h->S) dst[o] = st[i];           // slot -> original index of the shard
+            }
+        }
+    }
+    return LJMD_OK;
+}
+
 // stage[ax*P + slot] for the owned shard, slot order = current device order
 void stage_permuted(ljmd_t *h, const double *x, const double *y, const double *z, size_t off, double pad)
 {
@@ -713,7 +750,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMemsetAsync(h->d_ring_pos, 0, sizeof(unsigned), h->stream));
         LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, P3, h->stream));
         LJMD_HIP(h, hipMemsetAsync(h->d_ke_part, 0, 3 * (size_t)h->n_ke * sizeof(double), h->stream));
-        LJMD_HIP(h, hipHostMalloc(&h->h_stage, P3 * h->G, hipHostMallocDefault));
+        LJMD_HIP(h, hipHostMalloc(&h->h_stage, P3 * std::max(h->G, 4), hipHostMallocDefault));   // G position blocks, or r, ru, v, a
         LJMD_HIP(h, hipHostMalloc(&h->h_ring, (size_t)kRingCap * kPartialStride * sizeof(double),
                                   hipHostMallocDefault));
         LJMD_HIP(h, hipStreamSynchronize(h->stream));
@@ -861,25 +898,8 @@ int ljmd_get_state(ljmd_t *h, double *rx, double *ry, double *rz, double *ux, do
         return ljmdm::get_state(h, p);
     }
     LJMD_HIP(h, hipSetDevice(h->device));
-    int rc_ = refresh_perm(h);
-    if (rc_ != LJMD_OK) return rc_;
-    const size_t P = h->P;
-    const double *srcs[4] = {own_block(h), h->d_ru, h->d_v, h->d_a};
-    double *dsts[4][3] = {{rx, ry, rz}, {ux, uy, uz}, {vx, vy, vz}, {ax, ay, az}};
-    for (int w = 0; w < 4; ++w) {
-        if (!dsts[w][0] && !dsts[w][1] && !dsts[w][2]) continue;
-        LJMD_HIP(h, hipMemcpyAsync(h->h_stage, srcs[w], 3 * P * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        LJMD_HIP(h, hipStreamSynchronize(h->stream));
-        for (int k = 0; k < 3; ++k) {
-            if (!dsts[w][k]) continue;
-            const double *st = h->h_stage + k * P;
-            for (int i = 0; i < h->P; ++i) {
-                const int o = h->h_perm[i];
-                if (o < h->S) dsts[w][k][o] = st[i];   // slot -> original index of the shard
-            }
-        }
-    }
-    return LJMD_OK;
+    double *const dsts[12] = {rx, ry, rz, ux, uy, uz, vx, vy, vz, ax, ay, az};
+    return download_state(h, dsts, 0);
 }
 
 // ---- hot path ----------------------------------------------------------------
@@ -1428,12 +1448,22 @@ int ljmd_verlet_step(int32_t n, double box_length, double dt, double rc, double 
         if ((rc_ = ljmd_set_state(h, rx, ry, rz, vx, vy, vz)) != LJMD_OK) return rc_;
         if ((rc_ = ljmd_set_accel(h, ax, ay, az)) != LJMD_OK) return rc_;
     }
-    if ((rc_ = ljmd_verlet_steps(h, 1, epot, ekin, d_epot, dd_epot)) != LJMD_OK) return rc_;
-    rc_ = ljmd_get_state(h, rx, ry, rz, nullptr, nullptr, nullptr, vx, vy, vz, ax, ay, az);
+    // one step, then the scalar record and the nine arrays behind a single synchronisation
+    LJMD_HIP(h, hipSetDevice(h->device));
+    rc_ = enqueue_drift(h, nullptr);
+    if (rc_ == LJMD_OK) rc_ = enqueue_forces(h, true, nullptr);
+    if (rc_ != LJMD_OK) {
+        h->poisoned = true;
+        g_last_error = h->err;
+        return rc_;
+    }
+    double *const dsts[12] = {rx, ry, rz, nullptr, nullptr, nullptr, vx, vy, vz, ax, ay, az};
+    rc_ = download_state(h, dsts, 1);
     if (rc_ != LJMD_OK) {
         g_last_error = h->err;
         return rc_;
     }
+    combine_one(h, h->h_ring, 1, epot, ekin, d_epot, dd_epot);
     g_last_out.resize(9 * (size_t)n);
     for (int k = 0; k < 9; ++k) std::memcpy(g_last_out.data() + (size_t)k * n, arr[k], (size_t)n * sizeof(double));
     g_last_valid = true;

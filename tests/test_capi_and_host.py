@@ -143,3 +143,74 @@ def test_synthetic_configs_are_deterministic_and_sane():
     p3, r3, _ = synthetic.make_config(1048576 // 64, lattice="fcc")   # 4 * 16^3
     assert p3.n == 16384 and r3.shape == (3, 16384)
     assert synthetic.make_config(262144)[0].box_length == pytest.approx(68.941910081020, rel=1e-12)
+
+
+def test_host_code_under_sanitizers(tmp_path):
+    """libljmd.so's HOST code built with AddressSanitizer + UndefinedBehaviorSanitizer (`make -C csrc asan`; the
+    device code cannot be instrumented on this pool) driven through every entry point that is reachable without a
+    GPU: argument guards, the no-device failures of the single- and multi-device constructors and of the stateless
+    entry points, error-text plumbing, NULL handles.  Any sanitizer report fails the child process."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    lib = ROOT / "molecular-dynamics-simulation---lennard-jones-monoatomic-fluid_amd" / "csrc" / "obj" / "libljmd_asan.so"
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not lib.exists() or not rt:
+        pytest.skip("sanitizer build absent: make -C .../csrc asan")
+    script = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import numpy as np
+import ljmd_amd
+from ljmd_amd import _lib, md_types
+lib = _lib.load()
+assert "asan" in str(_lib.os.environ["LJMD_LIBRARY"])
+h = C.c_void_p()
+for args in ((0, 10.0, 0.005, 2.0), (10, -1.0, 0.005, 2.0), (10, 10.0, 0.005, 5.0), (10, 10.0, 0.0, 2.0)):
+    assert lib.ljmd_create(C.byref(h), *args, 0, 0, 0, 1) == _lib.LJMD_ERR_INVALID_ARG and _lib.last_error()
+assert lib.ljmd_create(C.byref(h), 10, 10.0, 0.005, 2.0, 0, 0, 0, 3) == _lib.LJMD_ERR_INVALID_ARG
+assert lib.ljmd_create(None, 10, 10.0, 0.005, 2.0, 0, 0, 0, 1) == _lib.LJMD_ERR_INVALID_ARG
+devs = (C.c_int32 * 4)(0, 0, 0, 0)
+nodev = lib.ljmd_device_count() == 0
+rc = lib.ljmd_create(C.byref(h), 4096, 20.0, 0.005, 8.0, 0, 0, 0, 1)
+assert rc == (_lib.LJMD_ERR_NO_DEVICE if nodev else 0)
+if rc == 0:
+    lib.ljmd_destroy(h)
+rc = lib.ljmd_create_multi(C.byref(h), 4096, 20.0, 0.005, 8.0, 0, 4, devs)
+assert rc == (_lib.LJMD_ERR_NO_DEVICE if nodev else 0), rc
+if rc == 0:
+    lib.ljmd_destroy(h)
+assert lib.ljmd_create_multi(C.byref(h), 4096, 20.0, 0.005, 8.0, 0, 0, None) == _lib.LJMD_ERR_INVALID_ARG
+assert lib.ljmd_create_multi(None, 4096, 20.0, 0.005, 8.0, 0, 2, None) == _lib.LJMD_ERR_INVALID_ARG
+p = md_types.init_params(108, 5.129927840030091, 0.005, 0.49 * 5.129927840030091)
+st = md_types.init_state(p)
+if nodev:
+    for fn in (ljmd_amd.compute_lj_potential_energy, ljmd_amd.verlet_step):
+        try:
+            fn(p, st)
+            raise SystemExit("expected LJMD_ERR_NO_DEVICE")
+        except ljmd_amd.LjmdError as e:
+            assert e.code == _lib.LJMD_ERR_NO_DEVICE
+    hist = (C.c_uint64 * 8)()
+    x = np.zeros(16)
+    dp = C.POINTER(C.c_double)
+    assert lib.ljmd_rdf_histogram(16, x.ctypes.data_as(dp), x.ctypes.data_as(dp), x.ctypes.data_as(dp), 10.0, 8, 4.0, hist) == _lib.LJMD_ERR_NO_DEVICE
+for fn in ("ljmd_set_state", "ljmd_get_state"):
+    pass
+assert lib.ljmd_compute_forces(None, None, None, None) == _lib.LJMD_ERR_INVALID_ARG
+assert lib.ljmd_verlet_steps(None, 1, None, None, None, None) == _lib.LJMD_ERR_INVALID_ARG
+assert lib.ljmd_snapshot_begin(None) == _lib.LJMD_ERR_INVALID_ARG
+assert lib.ljmd_comm_size(None) == 0
+assert lib.ljmd_comm_unique_id(None) == _lib.LJMD_ERR_INVALID_ARG
+lib.ljmd_destroy(None)
+lib.ljmd_stateless_reset()
+print("sanitized host code: ok")
+""" % str(ROOT)
+    env = dict(os.environ, LD_PRELOAD=rt[-1], LJMD_LIBRARY=str(lib),
+               ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:exitcode=23",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1:exitcode=24")
+    out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "sanitized host code: ok" in out.stdout
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error:" not in out.stderr
