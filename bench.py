@@ -136,6 +136,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles", dest="n", type=int, default=N_PARTICLES, help="override the particle count (parity/debug only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-liquid", action="store_true",
+                    help="skip the second, untimed-for-`value` measurement in the equilibrated liquid (300 extra steps)")
     ap.add_argument("--mode", choices=("fp64", "mixed"), default="fp64",
                     help="mixed = BASELINE config 5 (fp32 far pairs, fp64 near pairs + integrator); the headline metric is fp64")
     args = ap.parse_args()
@@ -215,10 +217,33 @@ def main() -> None:
     eng.profile_enable(False)
     epot, ekin, d_epot, dd_epot = sim.collect(args.steps)
 
+    # production rate: the same K steps timed again after the lattice has melted (>= 300 steps from the start).
+    # The tiles of a liquid are looser than those of the jittered lattice, so the tile mask keeps more pairs;
+    # reported beside the headline, never as `value`.
+    liquid = None
+    if not args.no_liquid and n >= 4096:
+        done = args.warmup + args.steps
+        while done < 300:
+            k = min(100, 300 - done)
+            sim.run(k)
+            done += k
+        eng.profile_enable(True)
+        barrier()
+        t1 = time.perf_counter()
+        sim.enqueue_steps(args.steps)
+        barrier()
+        el_liq = time.perf_counter() - t1
+        prof_liq = eng.profile_read()
+        eng.profile_enable(False)
+        sim.collect(args.steps)
+        liquid = (el_liq, prof_liq["pair_ms"], done)
+
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([elapsed, liquid[0] if liquid else 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if liquid:
+            liquid = (float(t[1].item()),) + liquid[1:]
 
     if rank == 0:
         steps_per_s = args.steps / elapsed
@@ -254,6 +279,11 @@ def main() -> None:
                          # unwrapped update incl. the amortised re-sort; slab reduction + second kick + finalize
                          "drift_kick_resort_ms_avg": prof["drift_ms"], "reduce_kick_finalize_ms_avg": prof["reduce_ms"],
                          "drift_kick_algorithmic_bytes": 168.0 * n / world},
+            **({"steps_per_s_liquid": args.steps / liquid[0],
+                "liquid": {"equilibration_steps": liquid[2], "ms_per_step": 1e3 * liquid[0] / args.steps,
+                           "pair_kernel_ms_avg": liquid[1],
+                           "note": "same K steps timed again in the equilibrated liquid; not the headline"}}
+               if liquid else {}),
             "energy_check": {"etot_first": float(etot[0]), "etot_last": float(etot[-1]),
                              "rel_drift": float(abs(etot[-1] - etot[0]) / abs(etot[0]))},
         }
@@ -271,14 +301,41 @@ def main() -> None:
                                            "algorithmic_bytes": 168.0 * n / world}
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
         # command (FETCH_SIZE and WRITE_SIZE need separate passes and cannot be read from inside the run)
-        pmc = ROOT / "profiles" / "r01_final_pmc_hbm_traffic.json"
-        if world == 1 and n == N_PARTICLES and pmc.exists():
+        def committed(stem):
+            """newest committed profile of that name (profiles/rNN_<stem>)"""
+            hits = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{stem}"))
+            return hits[-1] if hits else None
+
+        pmc = committed("final_pmc_hbm_traffic.json")
+        if world == 1 and n == N_PARTICLES and args.mode == "fp64" and pmc:
             kernels = json.loads(pmc.read_text())["kernels"]
             hits = [val for key, val in kernels.items() if key.startswith("ljmdk::" + kernel_name + "<")]
             k = max(hits, key=lambda val: val["hbm_bytes_per_launch"]) if hits else {}   # the template instance that ran
             if k:
                 line["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = "profiles/r01_final_pmc_hbm_traffic.json"
+                line["roofline"]["traffic_source"] = f"profiles/{pmc.name}"
+        # VALU issue evidence of the same command (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles)), PMC pass
+        valu = committed("final_pmc_valu.json")
+        if world == 1 and n == N_PARTICLES and args.mode == "fp64" and valu:
+            kernels = json.loads(valu.read_text())["kernels"]
+            hits = [val for key, val in kernels.items() if key.startswith("ljmdk::" + kernel_name + "<")]
+            k = max(hits, key=lambda val: val.get("SQ_INSTS_VALU", 0.0)) if hits else {}
+            if k.get("valu_issue_frac"):
+                line["roofline"].update({"valu_issue_frac": k["valu_issue_frac"],
+                                         "valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"],
+                                         "valu_source": f"profiles/{valu.name}"})
+        # K1 by the profiler's clock (a HIP-event interval around a 9 us kernel is mostly event overhead)
+        stats = committed("final_kernel_stats.csv")
+        if world == 1 and n == N_PARTICLES and stats and "roofline_hbm_kernel" in line:
+            import csv
+            for row in csv.DictReader(open(stats)):
+                if row["Name"].startswith("ljmdk::drift_kick_kernel"):
+                    ms = float(row["AverageNs"]) * 1e-6
+                    gbps = 168.0 * n / (ms * 1e-3) / 1e9
+                    line["roofline_hbm_kernel"].update({"rocprof_kernel_ms_avg": ms, "rocprof_achieved": gbps,
+                                                        "rocprof_frac": gbps / HBM_PEAK_GBPS,
+                                                        "rocprof_source": f"profiles/{stats.name}"})
+                    break
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

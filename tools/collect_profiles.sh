@@ -3,16 +3,19 @@
 #   1. rocprofv3 --kernel-trace --stats      -> per-kernel durations
 #   2. rocprofv3 --pmc FETCH_SIZE            -> HBM read traffic   } separate passes, --kernel-trace only,
 #   3. rocprofv3 --pmc WRITE_SIZE            -> HBM write traffic  } as MI355X_MICROARCH.md prescribes
+#   4. rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+#                                            -> VALU issue evidence of the fp64-bound pair kernel
 # and summarises them into gpurun_out/profiles_<tag>/ (copy what should be judged into profiles/).
 set -eo pipefail
 TAG=${1:-final}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+CMD="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-liquid"
 python3 bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 $CMD > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_fetch.log"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o run -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_write.log"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -o run -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-liquid > /dev/null 2> "$OUT/pmc_fetch.log"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -o run -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-liquid > /dev/null 2> "$OUT/pmc_write.log"
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_valu" -o run -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-liquid > /dev/null 2> "$OUT/pmc_valu.log"
 python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.log" 2>&1
 tail -5 "$OUT/summary.log"

@@ -2,6 +2,9 @@
 """Summarises the rocprofv3 output of tools/collect_profiles.sh:
    <dir>/kernel_stats.csv       per-kernel launch statistics (copied from the --stats pass)
    <dir>/pmc_hbm_traffic.json   per-kernel HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
+   <dir>/pmc_valu.json          per-kernel SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE
+                                per launch and the derived VALU issue fraction (wave-instructions x 4 cycles / (1024 SIMDs x
+                                kernel cycles)) -- the evidence behind "the fp64 pipe is saturated" 
 rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B read request and is
 doubled (MI355X_MICROARCH.md, HBM section)."""
 import csv
@@ -53,6 +56,40 @@ doc = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- pytho
        "gfx950_correction": "FETCH_SIZE doubled (MI355X_MICROARCH.md: reads tallied at 64 B per 128-B request)",
        "kernels": kernels}
 (out / "pmc_hbm_traffic.json").write_text(json.dumps(doc, indent=1))
+# ---- VALU issue evidence (optional pass) ----
+valu_dir = out / "pmc_valu"
+if valu_dir.exists() and list(valu_dir.rglob("*counter_collection.csv")):
+    N_SIMD = 256 * 4
+    N_XCD = 8          # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs of an MI355X (19.8 ms kernel -> 3.64e8)
+    vacc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(find("pmc_valu", "counter_collection.csv"))):
+        vacc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    vk = {}
+    for name, c in vacc.items():
+        if not name.startswith("ljmdk::"):
+            continue
+        m = {k: sum(v) / len(v) for k, v in c.items()}
+        m["launches"] = len(next(iter(c.values())))
+        cyc = m.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD
+        m["kernel_cycles"] = cyc
+        if cyc > 0 and "SQ_INSTS_VALU" in m:
+            m["valu_issue_frac"] = m["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * cyc)
+            m["cycles_per_valu_instruction_per_simd"] = N_SIMD * cyc / m["SQ_INSTS_VALU"]
+        if cyc > 0 and "SQ_ACTIVE_INST_VALU" in m:
+            # SQ_ACTIVE_INST_VALU: quad-cycles with a VALU instruction executing, summed over the SIMDs
+            m["valu_busy_frac"] = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cyc)
+        vk[name] = m
+    vdoc = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE "
+                       "--kernel-trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-liquid",
+            "units": "per-launch means; SQ_* summed over all shader engines / XCDs by rocprofv3; GRBM_GUI_ACTIVE = GPU-busy "
+                     "cycles of the dispatch summed over the 8 XCDs (kernel_cycles = GRBM_GUI_ACTIVE / 8)",
+            "valu_issue_frac": "SQ_INSTS_VALU (wave-instructions) x 4 cycles / (1024 SIMDs x kernel_cycles)",
+            "valu_busy_frac": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel_cycles)",
+            "kernels": vk}
+    (out / "pmc_valu.json").write_text(json.dumps(vdoc, indent=1))
+    for k, m in vk.items():
+        if k.startswith("ljmdk::pair_n3_kernel<"):
+            print(k, "SQ_INSTS_VALU %.4g" % m.get("SQ_INSTS_VALU", 0), "valu_issue_frac %.3f" % m.get("valu_issue_frac", 0))
 for k in kernels:
     if k.startswith(("ljmdk::pair_n3_kernel<", "ljmdk::drift_kick_kernel<", "ljmdk::reduce_forces_kernel<")):
         print(k, f"{kernels[k]['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch")
