@@ -135,6 +135,8 @@ ReduceArgs reduce_args(ljmd_t *h, int nslab, bool n3)
     a.NGo = h->NGo;
     a.Dmax = h->Dmax;
     a.Q = h->Q;
+    a.WG = h->wg_waves;
+    a.Q2 = h->Q2;
     a.RT = h->rt;
     return a;
 }
@@ -266,19 +268,20 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         LJMD_HIP(h, launch_tile_mask(ga, h->stream));
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
-            const dim3 grid(h->NGo, h->nslab_n);                                       // one wave per workgroup
-            LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->n3_waves, h->stream));   // all pairs, or the NEAR ones
+            const dim3 grid((h->NGo + h->wg_waves - 1) / h->wg_waves, h->nslab_n);     // wg_waves row groups per workgroup
+            LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->wg_waves, h->stream));   // all pairs, or the NEAR ones
             nslab = h->nslab_n;
-            n_wg = grid.x * grid.y;
+            n_wg = grid.x * grid.y * h->wg_waves;                                      // one partial per wave
             n3 = true;
             if (h->mode == LJMD_PRECISION_FP32_FORCE) {
-                const dim3 fgrid = grid;
+                const dim3 fgrid(h->NGo, h->nslab_n);                                  // one wave per workgroup
                 // far pass in fp32: its own row-side slices, column-side slab and workgroup partials
                 N3Args fa = n3_args(h);
                 fa.mask = h->d_mask_far;
                 fa.slab_i = h->d_slab + (size_t)h->nslab_n * 3 * h->P;
                 fa.slab_j = h->d_slab_j2;
                 fa.flag_j = h->d_flag_j2;
+                fa.Q = h->Q2;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
                 LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, h->stream));
                 nslab *= 2;
@@ -672,15 +675,31 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->NGo = h->TB / rt;
         h->NG = h->G * h->NGo;
         h->Dmax = h->NG / 2;
-        h->Q = (h->Dmax + 1) * rt;
+        // waves (= consecutive row groups) per pair-kernel workgroup: their column-side partial accelerations are
+        // combined in LDS, so the column slab holds one block per (workgroup, column tile) -- wg_waves times less
+        // memory and traffic.  Only for 4-tile row groups with plenty of them.
+        // Measured at n = 262144 (profiles/r02_wg_waves_lds_combine.txt): the lock step costs more than the smaller
+        // slab saves -- pair kernel 19.7 / 21.9 / 22.9 ms, slab reduction 0.63 / 0.41 / 0.29 ms for 1 / 2 / 4 --
+        // so the default stays 1 and a larger value is chosen only where the column slab would not fit a budget
+        // (LJMD_SLAB_BUDGET_GB, default 32: e.g. n = 1 048 576 on ONE GPU, 52 GB -> 13 GB with 4).
+        int wg = env_int("LJMD_N3_WG_WAVES", 0);
+        if (wg != 1 && wg != 2 && wg != 4) {
+            const double budget = 1e9 * std::max(1, env_int("LJMD_SLAB_BUDGET_GB", 32));
+            const double full = (double)h->NGo * (h->Dmax + 1) * rt * 3.0 * kTile * sizeof(double);
+            wg = full <= budget ? 1 : full <= 2.0 * budget ? 2 : 4;
+        }
+        if (rt != kRowTiles || h->NGo < 16 * wg) wg = 1;
+        h->wg_waves = wg;
+        h->Q = (h->Dmax + wg) * rt;
+        h->Q2 = (h->Dmax + 1) * rt;
         const int n3_min = env_int("LJMD_N3_MIN_N", 4096);
         h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min;
-        h->n3_waves = env_int("LJMD_N3_WAVES", 3);
         const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 131072));
         int ns = (target_waves + h->NGo - 1) / h->NGo;
-        ns = std::max(1, std::min(ns, h->Dmax + 1));
-        h->dchunk = (h->Dmax + 1 + ns - 1) / ns;
-        h->nslab_n = (h->Dmax + 1 + h->dchunk - 1) / h->dchunk;
+        const int n_off = h->Dmax + h->wg_waves;          // offsets a workgroup walks (relative to its first row group)
+        ns = std::max(1, std::min(ns, n_off));
+        h->dchunk = (n_off + ns - 1) / ns;
+        h->nslab_n = (n_off + h->dchunk - 1) / h->dchunk;
     }
     const bool mixed = precision_mode == LJMD_PRECISION_FP32_FORCE;
     if (mixed && (!h->use_n3 || n < kMixedMinN)) {
@@ -695,7 +714,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     }
     const int nslab_max = std::max(std::max(h->nslab_g, h->nslab_t), h->use_n3 ? h->nslab_n * (mixed ? 2 : 1) : 1);
     const int n_wg_max = std::max(row_blocks * std::max(h->nslab_g, h->nslab_t),
-                                  h->NGo * h->nslab_n * (mixed ? 2 : 1));
+                                  (h->NGo + 4) * h->nslab_n * (mixed ? 2 : 1));
     h->n_ke = row_blocks;
     h->h_perm.resize(h->P);
     for (int i = 0; i < h->P; ++i) h->h_perm[i] = i;
@@ -712,15 +731,16 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_slab, P3 * nslab_max));
         LJMD_HIP(h, hipMalloc(&h->d_wg_part, 2 * (size_t)n_wg_max * sizeof(double)));
         if (h->use_n3) {
-            LJMD_HIP(h, hipMalloc(&h->d_slab_j, (size_t)h->NGo * h->Q * 3 * kTile * sizeof(double)));
-            LJMD_HIP(h, hipMalloc(&h->d_flag_j, (size_t)h->NGo * h->Q));
-            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, (size_t)h->NGo * h->Q, h->stream));
+            const size_t n_blk = (size_t)((h->NGo + h->wg_waves - 1) / h->wg_waves) * h->Q;
+            LJMD_HIP(h, hipMalloc(&h->d_slab_j, n_blk * 3 * kTile * sizeof(double)));
+            LJMD_HIP(h, hipMalloc(&h->d_flag_j, n_blk));
+            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, n_blk, h->stream));
         }
         if (mixed) {
             LJMD_HIP(h, hipMalloc(&h->d_mask_far, (size_t)h->TB * h->W * sizeof(uint64_t)));
-            LJMD_HIP(h, hipMalloc(&h->d_slab_j2, (size_t)h->NGo * h->Q * 3 * kTile * sizeof(double)));
-            LJMD_HIP(h, hipMalloc(&h->d_flag_j2, (size_t)h->NGo * h->Q));
-            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j2, 0, (size_t)h->NGo * h->Q, h->stream));
+            LJMD_HIP(h, hipMalloc(&h->d_slab_j2, (size_t)h->NGo * h->Q2 * 3 * kTile * sizeof(double)));
+            LJMD_HIP(h, hipMalloc(&h->d_flag_j2, (size_t)h->NGo * h->Q2));
+            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j2, 0, (size_t)h->NGo * h->Q2, h->stream));
         }
         LJMD_HIP(h, hipMalloc(&h->d_fpart, P3 * (needs_force_exchange(h) ? h->G : 1)));
         if (needs_force_exchange(h)) LJMD_HIP(h, hipMalloc(&h->d_frecv, P3));

@@ -116,7 +116,8 @@ struct ljmd {
     int nslab_t = 1, chunk_t = 0;     // tile kernel:    grid (TB/4, nslab_t), chunk_t column tiles per slice
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
-    int n3_waves = 3;                 // LJMD_N3_WAVES: register-budget variant of the Newton-3 kernel
+    int wg_waves = 1;                 // LJMD_N3_WG_WAVES: row groups (waves) per pair-kernel workgroup (1, 2, 4)
+    int Q2 = 0;                       // column tiles per row group of the fp32 far pass (one wave per workgroup)
     int NG = 0, NGo = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
     int rt = kRowTiles;               // tiles per row group (LJMD_N3_ROW_TILES; auto: 4, or 2 / 1 for small systems)
     double *d_slab_j = nullptr;

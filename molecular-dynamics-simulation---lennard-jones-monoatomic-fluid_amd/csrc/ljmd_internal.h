@@ -54,8 +54,9 @@ struct N3Args {
     const uint64_t *mask;   // [TB rows][W] tile-pair mask of the owned row tiles
     const double *bbox;     // [T][kBoxStride] exact tile bounding boxes (image classification)
     double *slab_i;         // [nchunk][3][P] partial accelerations of the owned rows (row side)
-    double *slab_j;         // [NGo][Q][3][64] column-side partial accelerations, Q = (Dmax+1)*4
-    unsigned char *flag_j;  // [NGo][Q] 1 = slab_j block written this step
+    double *slab_j;         // [ceil(NGo/WG)][Q][3][64] column-side partial accelerations: one block per (workgroup of WG
+                            // consecutive row groups, column tile), Q = (Dmax + WG) * RT column tiles per workgroup
+    unsigned char *flag_j;  // [ceil(NGo/WG)][Q] 1 = slab_j block written this step
     double *wg_part;        // [n workgroups][2]
     int S, P, G, rank, TB, T, W;   // S = real particles per rank (slots S..P-1 are padding)
     int NG, NGo, Dmax, Q;   // row groups in total / owned by this rank (NGo = TB / RT, NG = G * NGo), Q = (Dmax+1)*RT
@@ -85,10 +86,11 @@ struct ReduceArgs {
     const double *slab;     // row side [nslab][3][P]
     const double *slab_j;   // column side (Newton-3) or NULL
     const unsigned char *flag_j;
-    const double *slab_j2;  // second column-side set (fp32 far pass of the mixed-precision mode) or NULL
+    const double *slab_j2;  // second column-side set (fp32 far pass of the mixed-precision mode: [NGo][Q2] blocks) or NULL
     const unsigned char *flag_j2;
     double *fpart;
     int nslab, P, G, rank, TB, NG, NGo, Dmax, Q;
+    int WG, Q2;             // row groups per pair-kernel workgroup (slab_j layout); Q2 = (Dmax + 1) * RT of the far pass
     int RT;                 // tiles per Newton-3 row group of this engine (1, 2 or 4)
 };
 
@@ -132,7 +134,7 @@ struct SortArgs {
 
 hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s);   // dispatches on a.RT
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s);   // dispatches on a.RT, wg_waves
 hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, int phase /* 0 all, 1 positions, 2 velocities */, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);

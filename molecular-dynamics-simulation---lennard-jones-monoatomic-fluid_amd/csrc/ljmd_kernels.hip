@@ -395,16 +395,38 @@ __device__ __forceinline__ bool uniform_image(double lo, double hi, double L, do
 __device__ unsigned long long g_variant_stats[64];
 #endif
 
-template <int MIN_WAVES, int RT>
-__global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
+// W waves per workgroup (W = 1, 2, 4): the W waves hold W CONSECUTIVE row groups and walk the same column tiles in
+// lock step -- wave w sees column group A0 + e at its own offset d = e - w -- so that their column-side partial
+// accelerations can be added through LDS (fixed order w = 0 .. W-1) and leave the chip as ONE slab_j block per
+// (workgroup, column tile) instead of one per (row group, column tile): W times less column-side slab memory and
+// traffic, and the column tile is fetched once per workgroup's L1 instead of once per wave.  One s_barrier per
+// column tile; comb[] is double-buffered so that wave 0's combine overlaps the other waves' next tile.
+template <int W>
+__device__ __forceinline__ void wave_lds_sync()
 {
-    // ONE wave per workgroup: the waves are independent, and a 4-wave workgroup would hold its CU slots
-    // until its slowest wave (different mask density per row group) has finished
-    __shared__ double parked[3 * kLdsAxis];                    // the current column tile, twice in a row per axis
-    const int lane = threadIdx.x;
-    const int Al = blockIdx.x;                                 // owned row group, wave-uniform
+    if constexpr (W == 1) {
+        __syncthreads();                                   // one wave per workgroup: orders this wave's own LDS traffic
+    } else {
+        // the parked tile is private to the wave and LDS executes a wave's instructions in order: only the
+        // compiler has to be kept from moving the reads across the writes
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int MIN_WAVES, int RT, int W>
+__global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
+{
+    __shared__ double parked_all[W][3 * kLdsAxis];             // per wave: the current column tile, twice in a row per axis
+    __shared__ double comb[W > 1 ? 2 : 1][W][3][W > 1 ? kTile : 1];
+    __shared__ int comb_on[2][W];
+    const int lane = threadIdx.x & 63;
+    const int wv = W == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double *parked = parked_all[wv];
+    const int Al = blockIdx.x * W + wv;                        // owned row group, wave-uniform
     const bool active = Al < a.NGo;
     const int A = a.rank * a.NGo + Al;                         // its global index
+    const int A0 = a.rank * a.NGo + blockIdx.x * W;            // the workgroup's first row group
     const size_t P = a.P;
     const double *own = a.pos + (size_t)a.rank * 3 * P;
 
@@ -437,15 +459,20 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
     }
 
     const bool group_full = (RT * Al + RT) * kTile <= a.S;   // no padding slot among the 256 rows
-    const int d0 = blockIdx.y * a.dchunk;
-    const int d1 = active ? min(d0 + a.dchunk, a.Dmax + 1) : d0;
-    for (int d = d0; d < d1; ++d) {
-        int B = A + d;
+    // e = offset of the column group from the workgroup's FIRST row group; wave w is at its own offset d = e - w.
+    // Every wave of the workgroup runs the same e and l trip counts (one barrier per column tile when W > 1).
+    const int e0 = blockIdx.y * a.dchunk;
+    const int e1 = min(e0 + a.dchunk, a.Dmax + W);
+    int buf = 0;
+    for (int e = e0; e < e1; ++e) {
+        const int d = e - wv;
+        const bool valid = active && d >= 0 && d <= a.Dmax;
+        int B = A0 + e;
         if (B >= a.NG) B -= a.NG;
-        const bool own = (d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B);
+        const bool own = valid && ((d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B));
         for (int l = 0; l < RT; ++l) {
             const int c = RT * B + l;                   // column tile (global)
-            const size_t blk = (size_t)Al * a.Q + (size_t)d * RT + l;
+            const size_t blk = (size_t)blockIdx.x * a.Q + (size_t)e * RT + l;
             unsigned mb = 0;
             if (own) {
 #pragma unroll
@@ -455,14 +482,12 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 }
                 if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
             }
-            if (mb == 0) {
-                if (lane == 0) a.flag_j[blk] = 0;
-                continue;
-            }
+            const bool have = mb != 0;
+            double jx = 0.0, jy = 0.0, jz = 0.0;
+            if (have) {
             const int gj = (a.G == 1) ? 0 : c / a.TB;          // rank block holding the column tile
             const double *cb = a.pos + (size_t)gj * 3 * P + (size_t)(c - gj * a.TB) * kTile + lane;
             double xj = cb[0], yj = cb[P], zj = cb[2 * P];
-            double jx = 0.0, jy = 0.0, jz = 0.0;
 
             // per axis: same periodic image for every pair of (row group, column tile)?  If so for all three,
             // also: is every pair provably INSIDE the cutoff (no test needed)?  Column box from bbox[].
@@ -518,15 +543,14 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 }
             } else {
 #if LJMD_LDS_POS
-                // one wave per workgroup: the barriers only order this wave's own LDS traffic
-                __syncthreads();                               // the previous tile's reads are done
+                wave_lds_sync<W>();                            // the previous tile's reads are done
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const double val = q == 0 ? xj : q == 1 ? yj : zj;
                     parked[q * kLdsAxis + lane] = val;
                     parked[q * kLdsAxis + kTile + lane] = val;
                 }
-                __syncthreads();
+                wave_lds_sync<W>();
 #endif
 #define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
     column_tile_loop<RT, NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
@@ -555,11 +579,44 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 else                  { if (all4) LJMD_LOOP(7, false, false); else LJMD_LOOP(7, true, false); }
 #undef LJMD_LOOP
             }
-            double *o = a.slab_j + blk * (3 * kTile) + lane;
-            o[0] = jx;
-            o[kTile] = jy;
-            o[2 * kTile] = jz;
-            if (lane == 0) a.flag_j[blk] = 1;
+            }   // have
+            if constexpr (W == 1) {
+                if (have) {
+                    double *o = a.slab_j + blk * (3 * kTile) + lane;
+                    o[0] = jx;
+                    o[kTile] = jy;
+                    o[2 * kTile] = jz;
+                }
+                if (lane == 0) a.flag_j[blk] = have ? 1 : 0;
+            } else {
+                if (have) {
+                    comb[buf][wv][0][lane] = jx;
+                    comb[buf][wv][1][lane] = jy;
+                    comb[buf][wv][2][lane] = jz;
+                }
+                if (lane == 0) comb_on[buf][wv] = have ? 1 : 0;
+                __syncthreads();
+                if (wv == 0) {
+                    double tx = 0.0, ty = 0.0, tz = 0.0;       // 0 + x == x: the first live wave's block passes unchanged
+                    bool any = false;
+#pragma unroll
+                    for (int w = 0; w < W; ++w)
+                        if (comb_on[buf][w]) {
+                            any = true;
+                            tx += comb[buf][w][0][lane];
+                            ty += comb[buf][w][1][lane];
+                            tz += comb[buf][w][2][lane];
+                        }
+                    if (any) {
+                        double *o = a.slab_j + blk * (3 * kTile) + lane;
+                        o[0] = tx;
+                        o[kTile] = ty;
+                        o[2 * kTile] = tz;
+                    }
+                    if (lane == 0) a.flag_j[blk] = any ? 1 : 0;
+                }
+                buf ^= 1;
+            }
         }
     }
 
@@ -575,7 +632,7 @@ __global__ __launch_bounds__(kTile, MIN_WAVES) void pair_n3_kernel(N3Args a)
     }
     const double t12 = wave_sum(s12), t6 = wave_sum(s6);
     if (lane == 0) {
-        double *w = a.wg_part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        double *w = a.wg_part + 2 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * W + wv);
         w[0] = t12;
         w[1] = t6;
     }
@@ -921,22 +978,33 @@ __global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
         const int c = g * a.TB + blockIdx.x;                    // global column tile (= this workgroup's tile)
         const int B = c / a.RT, l = c - B * a.RT;
         const int A0 = a.rank * a.NGo;
-        for (int Al = q; Al < a.NGo; Al += kWavesPerBlock) {
-            int d = B - (A0 + Al);
-            if (d < 0) d += a.NG;
-            if (d > a.Dmax) continue;
-            const size_t blk = (size_t)Al * a.Q + (size_t)d * a.RT + l;
+        // fp64 pass: one block per (pair-kernel workgroup of WG consecutive row groups, column tile)
+        const int nwg = (a.NGo + a.WG - 1) / a.WG;
+        for (int gi = q; gi < nwg; gi += kWavesPerBlock) {
+            int e = B - (A0 + gi * a.WG);
+            if (e < 0) e += a.NG;
+            if (e > a.Dmax + a.WG - 1) continue;
+            const size_t blk = (size_t)gi * a.Q + (size_t)e * a.RT + l;
             if (a.flag_j[blk]) {
                 const double *b = a.slab_j + blk * (3 * kTile) + lane;
                 s[0] += b[0];
                 s[1] += b[kTile];
                 s[2] += b[2 * kTile];
             }
-            if (a.slab_j2 && a.flag_j2[blk]) {
-                const double *b = a.slab_j2 + blk * (3 * kTile) + lane;
-                s[0] += b[0];
-                s[1] += b[kTile];
-                s[2] += b[2 * kTile];
+        }
+        // fp32 far pass of the mixed-precision mode: one block per (row group, column tile)
+        if (a.slab_j2) {
+            for (int Al = q; Al < a.NGo; Al += kWavesPerBlock) {
+                int d = B - (A0 + Al);
+                if (d < 0) d += a.NG;
+                if (d > a.Dmax) continue;
+                const size_t blk = (size_t)Al * a.Q2 + (size_t)d * a.RT + l;
+                if (a.flag_j2[blk]) {
+                    const double *b = a.slab_j2 + blk * (3 * kTile) + lane;
+                    s[0] += b[0];
+                    s[1] += b[kTile];
+                    s[2] += b[2 * kTile];
+                }
             }
         }
     }
@@ -1181,19 +1249,20 @@ hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int min_waves, hipStream_t s)
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s)
 {
-    // register budget variants (occupancy vs spills); the default is chosen by measurement
+    // 3 waves per SIMD (168 VGPRs, no spills) is the measured optimum of the register budget; wg_waves = waves
+    // (= consecutive row groups) per workgroup, 2 and 4 only for 4-tile row groups
     if (a.RT == 1)
-        hipLaunchKernelGGL((pair_n3_kernel<3, 1>), grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1>), grid, dim3(kTile), 0, s, a);
     else if (a.RT == 2)
-        hipLaunchKernelGGL((pair_n3_kernel<3, 2>), grid, dim3(kTile), 0, s, a);
-    else if (min_waves <= 3)
-        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles>), grid, dim3(kTile), 0, s, a);
-    else if (min_waves == 4)
-        hipLaunchKernelGGL((pair_n3_kernel<4, kRowTiles>), grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, 2, 1>), grid, dim3(kTile), 0, s, a);
+    else if (wg_waves == 4)
+        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 4>), grid, dim3(4 * kTile), 0, s, a);
+    else if (wg_waves == 2)
+        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 2>), grid, dim3(2 * kTile), 0, s, a);
     else
-        hipLaunchKernelGGL((pair_n3_kernel<5, kRowTiles>), grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 1>), grid, dim3(kTile), 0, s, a);
     return hipGetLastError();
 }
 
