@@ -482,6 +482,8 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 }
                 if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
             }
+            mb = (unsigned)__builtin_amdgcn_readfirstlane((int)mb);   // wave-uniform by construction: keep it in an SGPR so
+                                                                       // that the per-row-tile tests below are scalar branches
             const bool have = mb != 0;
             double jx = 0.0, jy = 0.0, jz = 0.0;
             if (have) {
