@@ -113,6 +113,16 @@ def config4():
                 "exchange_bytes_per_rank_per_step": 2 * 3 * 8 * (n // G)})
     for en in engines:
         en.close()
+    # the whole sharded system through the single-process multi-device handle (what md_simulation_gpu does with
+    # LJMD_GPUS=8), all eight ranks on this one card: peer-copy exchange, rank-ordered force sum
+    with Engine(p, devices=[0] * G) as multi:
+        multi.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e8 = multi.compute_forces()[0]
+        (e, k, _d, _dd), secs = timed_steps(multi, 2)
+        vel = np.stack(multi.get_state(("v",))["v"])
+    out.update({"multi_handle_8_ranks_one_card_epot_t0": e8, "multi_handle_epot_rel_diff_vs_one_rank": abs(e8 - out["epot_t0"]) / abs(out["epot_t0"]),
+                "multi_handle_8_ranks_one_card_ms_per_step": 1e3 * secs / 2,
+                "multi_handle_momentum_per_particle": float(np.abs(vel.sum(axis=1)).max() / n)})
     return out
 
 
