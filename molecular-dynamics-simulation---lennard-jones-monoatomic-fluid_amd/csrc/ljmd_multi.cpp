@@ -209,6 +209,7 @@ int create(ljmd_t **out, int32_t n, double box_length, double dt, double rc, int
             return rc_;
         }
         e->external_force_exchange = true;                // both exchanges are issued here, for all ranks at once
+        if (g > 0) e->inject_failure_at = -1;             // fault injection (tests): armed on rank 0 only
         m->eng.push_back(e);
     }
     // the parent carries the parameters the scalar combination needs (tail constants) and what callers query
@@ -283,7 +284,12 @@ int set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz, c
               const double *vz)
 {
     ljmd_multi *m = h->multi;
-    for (ljmd_t *e : m->eng) LJMD_CHILD(h, e, ljmd_set_state(e, rx, ry, rz, vx, vy, vz));
+    for (ljmd_t *e : m->eng) {
+        // after a batch that failed half-way the ranks are a phase apart: every rank drains its stream and
+        // re-synchronises its record ring with its own device count (ljmd_set_state on a poisoned engine)
+        if (h->poisoned) e->poisoned = true;
+        LJMD_CHILD(h, e, ljmd_set_state(e, rx, ry, rz, vx, vy, vz));
+    }
     h->have_state = true;
     h->have_accel = false;
     h->poisoned = false;

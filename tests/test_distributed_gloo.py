@@ -205,3 +205,27 @@ def test_world_size_one_needs_no_process_group(oracle):
     assert abs(e0 - ref[0]) < 1e-12 * abs(ref[0])
     e, k, d, dd = sim.run(3)
     assert e.shape == (3,) and np.all(np.isfinite(k))
+
+
+def test_bench_self_launch_spawns_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` with no launcher environment must start its two ranks itself (a child
+    torch.distributed.run, spawned before the parent touches torch or HIP) and exit with the child's code.  Without a
+    GPU the ranks fail loudly in ljmd_create (there is no CPU path), so here: non-zero exit, no JSON line on stdout,
+    the library's error text relayed on stderr.  (The success path is tests/test_gpu_sharded.py on the GPU box.)"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import ljmd_amd
+    from ljmd_amd import _lib
+    if _lib.load().ljmd_device_count() > 0:
+        pytest.skip("a HIP device is present: covered by tests/test_gpu_sharded.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--particles", "4096", "--no-cpu-baseline", "--no-liquid"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "no launcher environment: starting" in out.stderr
+    assert "torch.distributed.run" in out.stderr and "--nproc-per-node=2" in out.stderr
+    assert "no HIP device available" in out.stderr

@@ -310,3 +310,29 @@ def test_sharded_form_at_bench_size_eight_ranks_one_force_call():
     assert np.allclose(e8, e1, rtol=1e-12, atol=0), (e8, e1)
     assert np.abs(a8 - a1).max() <= 1e-12 * np.abs(a1).max()
     assert np.abs(a8.sum(axis=1)).max() <= 1e-9 * np.abs(a1).max()             # Newton 3 across ranks
+
+
+def test_multi_device_handle_poisoned_after_failed_batch_and_recovers(monkeypatch):
+    """A failure half-way through a step of the multi-device handle (injected in rank 0's force phase, after every
+    rank's drift and the position exchange) leaves the ranks a phase apart: the parent refuses to step until
+    ljmd_set_state, which re-synchronises every rank; afterwards the trajectory is the fresh one, bitwise."""
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+    p, r, v = synthetic.make_config(8192, seed=21)
+    with Engine(p, devices=[0, 0, 0, 0]) as ref:
+        ref.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e_ref = ref.compute_forces()
+        sc_ref = np.stack(ref.verlet_steps(12), axis=1)
+    monkeypatch.setenv("LJMD_INJECT_FAILURE_AT_STEP", "4")
+    with Engine(p, devices=[0, 0, 0, 0]) as eng:
+        monkeypatch.delenv("LJMD_INJECT_FAILURE_AT_STEP")
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert eng.compute_forces() == e_ref
+        with pytest.raises(ljmd_amd.LjmdError, match="injected failure"):
+            eng.verlet_steps(10)
+        with pytest.raises(ljmd_amd.LjmdError, match="poisoned"):
+            eng.verlet_steps(1)
+        with pytest.raises(ljmd_amd.LjmdError, match="poisoned"):
+            eng.compute_forces()
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert eng.compute_forces() == e_ref
+        assert np.array_equal(np.stack(eng.verlet_steps(12), axis=1), sc_ref)
