@@ -122,6 +122,29 @@ def test_thin_fortran_driver_config1(tmp_path):
     assert np.abs(s1[:, 0] - s2[:, 0]).max() < 1e-3
 
 
+@pytest.mark.parametrize("tag,n_rows,ranks", [("oi100", 9, "2"), ("oi10", 90, "4")])
+def test_thin_fortran_driver_several_ranks_from_one_process(tmp_path, tag, n_rows, ranks):
+    """north-star: "thin Fortran driver ... sharded across the GPUs".  LJMD_GPUS > 1 makes md_simulation_gpu create its
+    engine with ljmd_create_multi; everything else in the driver is the single-GPU code.  Here the ranks share this
+    box's one card (LJMD_DEVICES=0,0,...: peer-copy exchange); BASELINE config 1 against the reference's files with
+    the same bounds as the single-engine run, and the binary trajectory against the single-engine run's."""
+    import os
+    src = _workdir(tmp_path, tag)
+    env = dict(os.environ, LJMD_GPUS=ranks, LJMD_DEVICES=",".join(["0"] * int(ranks)))
+    out = subprocess.run([str(PKG / "bin" / "md_simulation_gpu")], cwd=tmp_path, check=True, capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert "steps/s" in out.stdout
+    _compare_run(tmp_path, src, n_rows)
+    _compare_statistics_files(tmp_path / "outputs" / "one_run", src)
+    h1, s1 = io_formats.read_rva(tmp_path / "outputs" / "one_run" / "rva.dat")
+    assert h1["n"] == 108 and s1.shape == (n_rows, 4, 3, 108)
+    if (src / "rva.dat").exists():
+        h2, s2 = io_formats.read_rva(src / "rva.dat")
+        assert h1 == h2
+        dev = [np.abs(s1[0, w] - s2[0, w]).max() for w in range(4)]
+        assert max(dev[:3]) < 1e-11 and dev[3] < 1e-11 * np.abs(s2[0, 3]).max()
+
+
 def test_thin_fortran_driver_error_convention(tmp_path):
     """Missing outputs/one_run -> the reference's `stop` message (md_simulation_program.f90:250)."""
     exe = PKG / "bin" / "md_simulation_gpu"
