@@ -116,3 +116,59 @@ def test_pair_kernels_on_half_box_ties_and_box_edges(oracle, kernel, monkeypatch
     # the pair at r = rc exactly contributes nothing: removing particle 7 changes particle 6's force only through
     # its other neighbours -- checked through the oracle, which is bit-pinned to the reference
     assert abs(r[0, 7] - r[0, 6]) == rc
+
+
+@pytest.mark.parametrize("kernel", ["generic", "tiles", "n3_1", "n3_2", "n3_4"])
+def test_ragged_and_tiny_systems_vs_oracle(oracle, kernel, monkeypatch):
+    """Edge sizes of every pair kernel against the oracle (= the reference's loop): n = 1 (no pair at all: the
+    reference's `do i = 1, n-1` does not execute, the scalars are the tail corrections alone), n = 2, 3, tile sizes
+    +-1 (63 / 64 / 65, 127 / 129, 255 / 257: padding slots in the last tile, partially filled row groups), a cutoff so
+    short that no pair is inside, a cutoff just below L/2, a dilute and a dense box -- seeded random gases with a
+    minimum separation so that no force overflows."""
+    if kernel == "generic":
+        monkeypatch.setenv("LJMD_FORCE_GENERIC", "1")
+    elif kernel == "tiles":
+        monkeypatch.setenv("LJMD_N3", "0")
+    else:
+        monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+        monkeypatch.setenv("LJMD_N3_ROW_TILES", kernel[-1])
+    rng = np.random.Generator(np.random.PCG64(2024))
+    cases = [(1, 6.0, 0.4), (2, 6.0, 0.45), (3, 5.0, 0.49), (63, 9.0, 0.49), (64, 9.0, 0.3), (65, 9.0, 0.49),
+             (127, 11.0, 0.49), (129, 11.0, 0.1), (255, 14.0, 0.49), (257, 14.0, 0.4999), (300, 30.0, 0.02),
+             (511, 9.5, 0.49), (513, 17.0, 0.49), (1000, 21.0, 0.35)]
+    for n, L, rc_over_L in cases:
+        # rejection-free placement with a minimum separation: jittered sub-lattice
+        m = int(np.ceil(n ** (1.0 / 3.0)))
+        cells = rng.permutation(m ** 3)[:n]
+        g = np.stack(np.unravel_index(cells, (m, m, m))).astype(np.float64)
+        r = np.ascontiguousarray((g + 0.5 + rng.uniform(-0.2, 0.2, g.shape)) * (L / m))
+        rc = rc_over_L * L
+        p = init_params(n, L, 0.005, rc)
+        po = oracle.derive_params(n, L, 0.005, rc)
+        e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+        ao = np.stack([ax, ay, az])
+        with Engine(p) as eng:
+            eng.set_state(r[0], r[1], r[2], r[0], r[1], r[2])
+            e, d, dd = eng.compute_forces()
+            a = np.stack(eng.get_state(("a",))["a"])
+            # two steps as well: drift / wrap / kick on ragged shards, scalars against the oracle's verlet_step
+            v = rng.uniform(-0.5, 0.5, r.shape)
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            eng.compute_forces()
+            sc = np.stack(eng.verlet_steps(2), axis=1)
+        st = {"rx": r[0].copy(), "ry": r[1].copy(), "rz": r[2].copy(), "ux": r[0].copy(), "uy": r[1].copy(),
+              "uz": r[2].copy(), "vx": v[0].copy(), "vy": v[1].copy(), "vz": v[2].copy(),
+              "ax": ax.copy(), "ay": ay.copy(), "az": az.copy()}
+        sc_o = oracle.run_steps(po, 2, st)
+        tag = (kernel, n, L, rc_over_L)
+        for name, mine, ref in (("epot", e, e_o), ("d_epot", d, d_o), ("dd_epot", dd, dd_o)):
+            assert abs(mine - ref) <= 1e-13 * max(abs(ref), 1e-300) + 1e-15, (tag, name, mine, ref)
+        assert np.abs(a - ao).max() <= 1e-12 * max(np.abs(ao).max(), 1e-3), tag
+        assert np.max(np.abs(sc - sc_o) / np.maximum(np.abs(sc_o), 1e-12)) < 1e-10, (tag, sc, sc_o)
+    if kernel == "tiles":
+        # n = 1: nothing but the tail terms (lj_potential_energy.f90:205-223)
+        p1 = init_params(1, 6.0, 0.005, 2.4)
+        with Engine(p1) as eng:
+            z = np.array([1.0])
+            eng.set_state(z, z, z, z, z, z)
+            assert eng.compute_forces() == oracle.tail_corrections(oracle.derive_params(1, 6.0, 0.005, 2.4))
