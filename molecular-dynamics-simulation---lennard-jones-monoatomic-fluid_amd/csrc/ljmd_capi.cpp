@@ -89,6 +89,7 @@ N3Args n3_args(ljmd_t *h)
     a.Dmax = h->Dmax;
     a.Q = h->Q;
     a.dchunk = h->dchunk;
+    a.xcd_remap = 0;
     a.RT = h->rt;
     a.L = h->L;
     a.invL = h->invL;
@@ -269,7 +270,9 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
             const dim3 grid((h->NGo + h->wg_waves - 1) / h->wg_waves, h->nslab_n);     // wg_waves row groups per workgroup
-            LJMD_HIP(h, launch_pair_n3(n3_args(h), grid, h->wg_waves, h->stream));   // all pairs, or the NEAR ones
+            N3Args na = n3_args(h);
+            na.xcd_remap = (h->xcd_remap > 0 && grid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
+            LJMD_HIP(h, launch_pair_n3(na, grid, h->wg_waves, h->stream));            // all pairs, or the NEAR ones
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y * h->wg_waves;                                      // one partial per wave
             n3 = true;
@@ -612,6 +615,9 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
     h->force_collectives = env_int("LJMD_FORCE_COLLECTIVES", 0) != 0;
     h->fuse_small = env_int("LJMD_FUSE", 1) != 0;
+    // measured at n = 262144: chunks of 4 consecutive row groups per XCD -3 % pair-kernel time (19.8 -> 19.1 ms; 2: -1 %,
+    // 8 / 16 / 32: +-0, one contiguous eighth per XCD: +10 %), -1.5 % at n = 131072 and 524288 (profiles/r02_xcd_remap_and_prefetch.txt)
+    h->xcd_remap = std::max(0, env_int("LJMD_N3_XCD_REMAP", 4));
     h->inject_failure_at = env_int("LJMD_INJECT_FAILURE_AT_STEP", -1);
     {
         const char *fx = std::getenv("LJMD_FORCE_EXCHANGE");

@@ -414,19 +414,174 @@ __device__ __forceinline__ void wave_lds_sync()
     }
 }
 
+// One column tile against the wave's RT row tiles: image classification, then the 64 rotation steps in the loop
+// variant that fits.  PREFETCHED = the tile's positions already lie in `parked` (LDS-DMA issued one tile earlier);
+// otherwise they are loaded here and parked.  after_classification() is called between the classification (whose
+// loads are consumed by then) and the rotation loop (which touches LDS only): the place to issue the NEXT tile's
+// LDS-DMA so that it overlaps the whole loop and no later s_waitcnt vmcnt of this tile has to wait for it.
+template <int RT, int W, bool PREFETCHED, typename AFTER>
+__device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, int d, int l, unsigned mb, bool group_full,
+                                             const double (&glo)[3], const double (&ghi)[3], const double (&xi)[RT],
+                                             const double (&yi)[RT], const double (&zi)[RT], double (&ax)[RT],
+                                             double (&ay)[RT], double (&az)[RT], double *parked, AFTER &&after_classification,
+                                             double &jx, double &jy, double &jz, double &s12, double &s6)
+{
+    const size_t P = a.P;
+    double xj, yj, zj;
+    if constexpr (PREFETCHED) {
+        xj = parked[lane];
+        yj = parked[kLdsAxis + lane];
+        zj = parked[2 * kLdsAxis + lane];
+    } else {
+        const int gj = (a.G == 1) ? 0 : c / a.TB;          // rank block holding the column tile
+        const double *cb = a.pos + (size_t)gj * 3 * P + (size_t)(c - gj * a.TB) * kTile + lane;
+        xj = cb[0]; yj = cb[P]; zj = cb[2 * P];
+    }
+
+    // per axis: same periodic image for every pair of (row group, column tile)?  If so for all three,
+    // also: is every pair provably INSIDE the cutoff (no test needed)?  Column box from bbox[].
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    int nu;
+    bool inner;
+    {
+        const double *cbx = a.bbox + (size_t)c * kBoxStride;
+        const double lo[3] = {glo[0] - cbx[3], glo[1] - cbx[4], glo[2] - cbx[5]};
+        const double hi[3] = {ghi[0] - cbx[0], ghi[1] - cbx[1], ghi[2] - cbx[2]};
+        const bool ux = uniform_image(lo[0], hi[0], a.L, a.invL, sx);
+        const bool uy = uniform_image(lo[1], hi[1], a.L, a.invL, sy);
+        const bool uz = uniform_image(lo[2], hi[2], a.L, a.invL, sz);
+        nu = __builtin_amdgcn_readfirstlane((ux ? 0 : 1) | (uy ? 0 : 2) | (uz ? 0 : 4));
+        const double fx = fmax(fabs(lo[0] - sx), fabs(hi[0] - sx)), fy = fmax(fabs(lo[1] - sy), fabs(hi[1] - sy)),
+                     fz = fmax(fabs(lo[2] - sz), fabs(hi[2] - sz));
+        // padding slots (NaN) must keep failing the cutoff test: INNER only for completely filled tiles
+        const bool full = group_full && ((c - (a.G == 1 ? 0 : c / a.TB) * a.TB) + 1) * kTile <= a.S;
+        inner = __builtin_amdgcn_readfirstlane(
+                    (int)(nu == 0 && full && (fx * fx + fy * fy + fz * fz) < a.rc2 * (1.0 - 1e-10))) != 0;
+        if (nu & 1) sx = 0.0;
+        if (nu & 2) sy = 0.0;
+        if (nu & 4) sz = 0.0;
+        if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
+        if (nu == 1 && sy == 0.0 && sz == 0.0) nu = 24;          // one general axis, no image on the others
+        else if (nu == 2 && sx == 0.0 && sz == 0.0) nu = 25;
+        else if (nu == 4 && sx == 0.0 && sy == 0.0) nu = 26;
+        nu = __builtin_amdgcn_readfirstlane(nu);
+        if (nu == 0) {
+            const int nz = __builtin_amdgcn_readfirstlane((sx != 0.0 ? 1 : 0) | (sy != 0.0 ? 2 : 0) | (sz != 0.0 ? 4 : 0));
+            nu = nz == 0 ? 8 : nz == 1 ? 16 : nz == 2 ? 17 : nz == 4 ? 18 : 0;   // none / one axis / several
+        }
+    }
+    after_classification();
+
+    if (d == 0 && ((mb >> l) & 1u)) {
+        // the column tile is one of the wave's own row tiles: tile l against itself
+        for (int s = 0; s < kTile; ++s) {
+#pragma unroll
+            for (int k = 0; k < RT; ++k) {
+                if (!((mb >> k) & 1u)) continue;
+                if (k == l) {
+                    if (s >= 1 && s <= 32)
+                        pair_n3<true, 7>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2,
+                                         s < 32 || lane < 32, 0.0, 0.0, 0.0, ax[k], ay[k], az[k], jx,
+                                         jy, jz, s12, s6);
+                } else {
+                    pair_n3<false, 7>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0,
+                                      0.0, 0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+                }
+            }
+            xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
+            jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
+        }
+        return;
+    }
+#if LJMD_LDS_POS
+    if constexpr (!PREFETCHED) {
+        wave_lds_sync<W>();                            // the previous tile's reads are done
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double val = q == 0 ? xj : q == 1 ? yj : zj;
+            parked[q * kLdsAxis + lane] = val;
+            parked[q * kLdsAxis + kTile + lane] = val;
+        }
+        wave_lds_sync<W>();
+    }
+#endif
+#define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
+    column_tile_loop<RT, NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
+                                           a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
+    const bool all4 = mb == ((1u << RT) - 1u);
+#ifdef LJMD_VARIANT_STATS
+    if (lane == 0)          // measurement build only (tools/variant_stats.py): row tiles evaluated per class
+        atomicAdd(&g_variant_stats[(nu & 31) * 2 + (inner ? 1 : 0)], (unsigned long long)__builtin_popcount(mb));
+#endif
+    if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
+    else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
+    else if (nu == 16 && inner) { if (all4) LJMD_LOOP(16, false, true); else LJMD_LOOP(16, true, true); }
+    else if (nu == 16)    { if (all4) LJMD_LOOP(16, false, false); else LJMD_LOOP(16, true, false); }
+    else if (nu == 17 && inner) { if (all4) LJMD_LOOP(17, false, true); else LJMD_LOOP(17, true, true); }
+    else if (nu == 17)    { if (all4) LJMD_LOOP(17, false, false); else LJMD_LOOP(17, true, false); }
+    else if (nu == 18 && inner) { if (all4) LJMD_LOOP(18, false, true); else LJMD_LOOP(18, true, true); }
+    else if (nu == 18)    { if (all4) LJMD_LOOP(18, false, false); else LJMD_LOOP(18, true, false); }
+    else if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
+    else if (nu == 0)     { if (all4) LJMD_LOOP(0, false, false); else LJMD_LOOP(0, true, false); }
+    else if (nu == 24)    { if (all4) LJMD_LOOP(24, false, false); else LJMD_LOOP(24, true, false); }
+    else if (nu == 25)    { if (all4) LJMD_LOOP(25, false, false); else LJMD_LOOP(25, true, false); }
+    else if (nu == 26)    { if (all4) LJMD_LOOP(26, false, false); else LJMD_LOOP(26, true, false); }
+    else if (nu == 1)     { if (all4) LJMD_LOOP(1, false, false); else LJMD_LOOP(1, true, false); }
+    else if (nu == 2)     { if (all4) LJMD_LOOP(2, false, false); else LJMD_LOOP(2, true, false); }
+    else if (nu == 4)     { if (all4) LJMD_LOOP(4, false, false); else LJMD_LOOP(4, true, false); }
+    else                  { if (all4) LJMD_LOOP(7, false, false); else LJMD_LOOP(7, true, false); }
+#undef LJMD_LOOP
+}
+
+// LDS-DMA of one column tile: per axis ONE global_load_lds_dwordx4 -- lane l fetches 16 bytes (two doubles) of the
+// 512-byte axis at offset 16 (l & 31) and the hardware stores lane l's data at LDS base + 16 l, so lanes 0..31 and
+// 32..63 park the axis twice in a row, the layout column_tile_loop reads (tools/check_lds_dma.hip).  No VGPR is
+// involved and nothing waits: completion is observed through vmcnt.
+__device__ __forceinline__ void tile_to_lds_async(const N3Args &a, int lane, int c, double *parked)
+{
+    const size_t P = a.P;
+    const int gj = (a.G == 1) ? 0 : c / a.TB;
+    const double *cb = a.pos + (size_t)gj * 3 * P + (size_t)(c - gj * a.TB) * kTile + 2 * (lane & 31);
+    __builtin_amdgcn_global_load_lds(cb, parked, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(cb + P, parked + kLdsAxis, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(cb + 2 * P, parked + 2 * kLdsAxis, 16, 0, 0);
+}
+
+// Measured (profiles/r02_xcd_remap_and_prefetch.txt): with the next tile prefetched the pair kernel takes 19.16 ms,
+// without 19.05-19.26 ms -- the two other waves of a SIMD already hide the tile fetch.  Parity-green
+// (make EXTRA=-DLJMD_PREFETCH=1), kept out of the default build.
+#ifndef LJMD_PREFETCH
+#define LJMD_PREFETCH 0
+#endif
+
 template <int MIN_WAVES, int RT, int W>
 __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
 {
-    __shared__ double parked_all[W][3 * kLdsAxis];             // per wave: the current column tile, twice in a row per axis
+    constexpr bool kPrefetch = (W == 1) && LJMD_PREFETCH && LJMD_LDS_POS;
+    __shared__ double parked_all[W][kPrefetch ? 2 : 1][3 * kLdsAxis];   // per wave: column tile(s), twice in a row per axis
     __shared__ double comb[W > 1 ? 2 : 1][W][3][W > 1 ? kTile : 1];
     __shared__ int comb_on[2][W];
     const int lane = threadIdx.x & 63;
     const int wv = W == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    double *parked = parked_all[wv];
-    const int Al = blockIdx.x * W + wv;                        // owned row group, wave-uniform
+    // XCD-aware work mapping: the hardware deals workgroups round-robin over the 8 XCDs (b and b + 8 share one, each
+    // XCD has its own L2).  With the plain mapping the row groups A, A+1, ... that read the same column tiles (B = A + d
+    // for the few d of a slice) sit on 8 different XCDs and every one of them fetches the tile through the fabric.
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd_remap) {                                         // host guarantees gridDim.x % (8 * chunk) == 0
+        // an XCD takes chunks of `xcd_remap` consecutive row groups, the chunks dealt round-robin over the XCDs: the
+        // row groups inside a chunk share their column tiles through the XCD's L2, while every XCD still sees the same
+        // statistical mix of heavy and light work items at any time (ONE contiguous eighth per XCD measured 10 %
+        // slower: for a given slice the work of neighbouring row groups is correlated, and an XCD that holds only
+        // heavy items stalls the round-robin dispatcher for the others)
+        const unsigned id = blockIdx.y * gridDim.x + blockIdx.x, per = gridDim.x >> 3, C = (unsigned)a.xcd_remap;
+        const unsigned xcd = id & 7u, slot = id >> 3, s = slot % per;
+        by = slot / per;
+        bx = ((s / C) * 8u + xcd) * C + s % C;
+    }
+    const int Al = (int)bx * W + wv;                           // owned row group, wave-uniform
     const bool active = Al < a.NGo;
     const int A = a.rank * a.NGo + Al;                         // its global index
-    const int A0 = a.rank * a.NGo + blockIdx.x * W;            // the workgroup's first row group
+    const int A0 = a.rank * a.NGo + (int)bx * W;               // the workgroup's first row group
     const size_t P = a.P;
     const double *own = a.pos + (size_t)a.rank * 3 * P;
 
@@ -461,127 +616,82 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
     const bool group_full = (RT * Al + RT) * kTile <= a.S;   // no padding slot among the 256 rows
     // e = offset of the column group from the workgroup's FIRST row group; wave w is at its own offset d = e - w.
     // Every wave of the workgroup runs the same e and l trip counts (one barrier per column tile when W > 1).
-    const int e0 = blockIdx.y * a.dchunk;
+    const int e0 = (int)by * a.dchunk;
     const int e1 = min(e0 + a.dchunk, a.Dmax + W);
-    int buf = 0;
-    for (int e = e0; e < e1; ++e) {
-        const int d = e - wv;
+
+    // tile t = (e - e0) * RT + l of this work item: its column tile c, offset d, slab block, and the mask bits of the
+    // wave's RT row tiles (0 = nothing to do: not owned, or every row tile proven outside the cutoff)
+    auto tile_of = [&](int t, int &c, int &d, int &l, size_t &blk) -> unsigned {
+        const int e = e0 + t / RT;
+        l = t - (t / RT) * RT;
+        d = e - wv;
         const bool valid = active && d >= 0 && d <= a.Dmax;
         int B = A0 + e;
         if (B >= a.NG) B -= a.NG;
-        const bool own = valid && ((d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B));
-        for (int l = 0; l < RT; ++l) {
-            const int c = RT * B + l;                   // column tile (global)
-            const size_t blk = (size_t)blockIdx.x * a.Q + (size_t)e * RT + l;
-            unsigned mb = 0;
-            if (own) {
+        const bool owned = valid && ((d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B));
+        c = RT * B + l;                                 // column tile (global)
+        blk = (size_t)bx * a.Q + (size_t)e * RT + l;
+        unsigned mb = 0;
+        if (owned) {
 #pragma unroll
-                for (int k = 0; k < RT; ++k) {
-                    const uint64_t w = a.mask[(size_t)(RT * Al + k) * a.W + (c >> 6)];
-                    mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
-                }
-                if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
+            for (int k = 0; k < RT; ++k) {
+                const uint64_t w = a.mask[(size_t)(RT * Al + k) * a.W + (c >> 6)];
+                mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
             }
-            mb = (unsigned)__builtin_amdgcn_readfirstlane((int)mb);   // wave-uniform by construction: keep it in an SGPR so
-                                                                       // that the per-row-tile tests below are scalar branches
+            if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
+        }
+        // wave-uniform by construction: keep it in an SGPR so that the per-row-tile tests are scalar branches
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)mb);
+    };
+    const int nt = (e1 - e0) * RT;
+
+    if constexpr (kPrefetch) {
+        // one wave per workgroup: walk the KEPT tiles only, the next kept tile's positions in flight (LDS-DMA into the
+        // other parking buffer) while the current tile's 64 rotation steps run
+        auto next_kept = [&](int t, int &c, int &d, int &l, size_t &blk, unsigned &mb) -> int {
+            for (; t < nt; ++t) {
+                mb = tile_of(t, c, d, l, blk);
+                if (mb) break;
+                if (lane == 0) a.flag_j[blk] = 0;
+            }
+            return t;
+        };
+        int c, d, l, cn = 0, dn = 0, ln = 0;
+        size_t blk, blkn = 0;
+        unsigned mb = 0, mbn = 0;
+        int t = next_kept(0, c, d, l, blk, mb);
+        int cur = 0;
+        if (t < nt) tile_to_lds_async(a, lane, c, parked_all[0][0]);
+        while (t < nt) {
+            const int tn = next_kept(t + 1, cn, dn, ln, blkn, mbn);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t has landed (issued one tile ago)
+            __builtin_amdgcn_wave_barrier();
+            double jx = 0.0, jy = 0.0, jz = 0.0;
+            double *pk_cur = cur ? parked_all[0][1] : parked_all[0][0];
+            double *pk_next = cur ? parked_all[0][0] : parked_all[0][1];
+            n3_tile_pass<RT, W, true>(a, lane, c, d, l, mb, group_full, glo, ghi, xi, yi, zi, ax, ay, az, pk_cur,
+                                      [&]() { if (tn < nt) tile_to_lds_async(a, lane, cn, pk_next); },
+                                      jx, jy, jz, s12, s6);
+            double *o = a.slab_j + blk * (3 * kTile) + lane;
+            o[0] = jx;
+            o[kTile] = jy;
+            o[2 * kTile] = jz;
+            if (lane == 0) a.flag_j[blk] = 1;
+            t = tn; c = cn; d = dn; l = ln; blk = blkn; mb = mbn;
+            cur ^= 1;
+        }
+    } else {
+        double *parked = parked_all[wv][0];
+        int buf = 0;
+        for (int t = 0; t < nt; ++t) {
+            int c, d, l;
+            size_t blk;
+            const unsigned mb = tile_of(t, c, d, l, blk);
             const bool have = mb != 0;
             double jx = 0.0, jy = 0.0, jz = 0.0;
-            if (have) {
-            const int gj = (a.G == 1) ? 0 : c / a.TB;          // rank block holding the column tile
-            const double *cb = a.pos + (size_t)gj * 3 * P + (size_t)(c - gj * a.TB) * kTile + lane;
-            double xj = cb[0], yj = cb[P], zj = cb[2 * P];
-
-            // per axis: same periodic image for every pair of (row group, column tile)?  If so for all three,
-            // also: is every pair provably INSIDE the cutoff (no test needed)?  Column box from bbox[].
-            double sx = 0.0, sy = 0.0, sz = 0.0;
-            int nu;
-            bool inner;
-            {
-                const double *cbx = a.bbox + (size_t)c * kBoxStride;
-                const double lo[3] = {glo[0] - cbx[3], glo[1] - cbx[4], glo[2] - cbx[5]};
-                const double hi[3] = {ghi[0] - cbx[0], ghi[1] - cbx[1], ghi[2] - cbx[2]};
-                const bool ux = uniform_image(lo[0], hi[0], a.L, a.invL, sx);
-                const bool uy = uniform_image(lo[1], hi[1], a.L, a.invL, sy);
-                const bool uz = uniform_image(lo[2], hi[2], a.L, a.invL, sz);
-                nu = __builtin_amdgcn_readfirstlane((ux ? 0 : 1) | (uy ? 0 : 2) | (uz ? 0 : 4));
-                const double fx = fmax(fabs(lo[0] - sx), fabs(hi[0] - sx)), fy = fmax(fabs(lo[1] - sy), fabs(hi[1] - sy)),
-                             fz = fmax(fabs(lo[2] - sz), fabs(hi[2] - sz));
-                // padding slots (NaN) must keep failing the cutoff test: INNER only for completely filled tiles
-                const bool full = group_full && ((c - (a.G == 1 ? 0 : c / a.TB) * a.TB) + 1) * kTile <= a.S;
-                inner = __builtin_amdgcn_readfirstlane(
-                            (int)(nu == 0 && full && (fx * fx + fy * fy + fz * fz) < a.rc2 * (1.0 - 1e-10))) != 0;
-                if (nu & 1) sx = 0.0;
-                if (nu & 2) sy = 0.0;
-                if (nu & 4) sz = 0.0;
-                if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
-                if (nu == 1 && sy == 0.0 && sz == 0.0) nu = 24;          // one general axis, no image on the others
-                else if (nu == 2 && sx == 0.0 && sz == 0.0) nu = 25;
-                else if (nu == 4 && sx == 0.0 && sy == 0.0) nu = 26;
-                nu = __builtin_amdgcn_readfirstlane(nu);
-                if (nu == 0) {
-                    const int nz = __builtin_amdgcn_readfirstlane((sx != 0.0 ? 1 : 0) | (sy != 0.0 ? 2 : 0) | (sz != 0.0 ? 4 : 0));
-                    nu = nz == 0 ? 8 : nz == 1 ? 16 : nz == 2 ? 17 : nz == 4 ? 18 : 0;   // none / one axis / several
-                }
-            }
-
-            if (d == 0 && ((mb >> l) & 1u)) {
-                // the column tile is one of the wave's own row tiles: tile l against itself
-                for (int s = 0; s < kTile; ++s) {
-#pragma unroll
-                    for (int k = 0; k < RT; ++k) {
-                        if (!((mb >> k) & 1u)) continue;
-                        if (k == l) {
-                            if (s >= 1 && s <= 32)
-                                pair_n3<true, 7>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2,
-                                                 s < 32 || lane < 32, 0.0, 0.0, 0.0, ax[k], ay[k], az[k], jx,
-                                                 jy, jz, s12, s6);
-                        } else {
-                            pair_n3<false, 7>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0,
-                                              0.0, 0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
-                        }
-                    }
-                    xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
-                    jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
-                }
-            } else {
-#if LJMD_LDS_POS
-                wave_lds_sync<W>();                            // the previous tile's reads are done
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const double val = q == 0 ? xj : q == 1 ? yj : zj;
-                    parked[q * kLdsAxis + lane] = val;
-                    parked[q * kLdsAxis + kTile + lane] = val;
-                }
-                wave_lds_sync<W>();
-#endif
-#define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
-    column_tile_loop<RT, NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
-                                           a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
-                const bool all4 = mb == ((1u << RT) - 1u);
-#ifdef LJMD_VARIANT_STATS
-                if (lane == 0)          // measurement build only (tools/variant_stats.py): row tiles evaluated per class
-                    atomicAdd(&g_variant_stats[(nu & 31) * 2 + (inner ? 1 : 0)], (unsigned long long)__builtin_popcount(mb));
-#endif
-                if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
-                else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
-                else if (nu == 16 && inner) { if (all4) LJMD_LOOP(16, false, true); else LJMD_LOOP(16, true, true); }
-                else if (nu == 16)    { if (all4) LJMD_LOOP(16, false, false); else LJMD_LOOP(16, true, false); }
-                else if (nu == 17 && inner) { if (all4) LJMD_LOOP(17, false, true); else LJMD_LOOP(17, true, true); }
-                else if (nu == 17)    { if (all4) LJMD_LOOP(17, false, false); else LJMD_LOOP(17, true, false); }
-                else if (nu == 18 && inner) { if (all4) LJMD_LOOP(18, false, true); else LJMD_LOOP(18, true, true); }
-                else if (nu == 18)    { if (all4) LJMD_LOOP(18, false, false); else LJMD_LOOP(18, true, false); }
-                else if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
-                else if (nu == 0)     { if (all4) LJMD_LOOP(0, false, false); else LJMD_LOOP(0, true, false); }
-                else if (nu == 24)    { if (all4) LJMD_LOOP(24, false, false); else LJMD_LOOP(24, true, false); }
-                else if (nu == 25)    { if (all4) LJMD_LOOP(25, false, false); else LJMD_LOOP(25, true, false); }
-                else if (nu == 26)    { if (all4) LJMD_LOOP(26, false, false); else LJMD_LOOP(26, true, false); }
-                else if (nu == 1)     { if (all4) LJMD_LOOP(1, false, false); else LJMD_LOOP(1, true, false); }
-                else if (nu == 2)     { if (all4) LJMD_LOOP(2, false, false); else LJMD_LOOP(2, true, false); }
-                else if (nu == 4)     { if (all4) LJMD_LOOP(4, false, false); else LJMD_LOOP(4, true, false); }
-                else                  { if (all4) LJMD_LOOP(7, false, false); else LJMD_LOOP(7, true, false); }
-#undef LJMD_LOOP
-            }
-            }   // have
+            if (have)
+                n3_tile_pass<RT, W, false>(a, lane, c, d, l, mb, group_full, glo, ghi, xi, yi, zi, ax, ay, az, parked,
+                                           []() {}, jx, jy, jz, s12, s6);
             if constexpr (W == 1) {
                 if (have) {
                     double *o = a.slab_j + blk * (3 * kTile) + lane;
@@ -623,7 +733,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
     }
 
     if (active) {
-        double *si = a.slab_i + (size_t)blockIdx.y * 3 * P;
+        double *si = a.slab_i + (size_t)by * 3 * P;
 #pragma unroll
         for (int k = 0; k < RT; ++k) {
             const size_t slot = (size_t)(RT * Al + k) * kTile + lane;
@@ -634,7 +744,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
     }
     const double t12 = wave_sum(s12), t6 = wave_sum(s6);
     if (lane == 0) {
-        double *w = a.wg_part + 2 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * W + wv);
+        double *w = a.wg_part + 2 * (((size_t)by * gridDim.x + bx) * W + wv);
         w[0] = t12;
         w[1] = t6;
     }
