@@ -271,7 +271,9 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (h->use_n3) {
             const dim3 grid((h->NGo + h->wg_waves - 1) / h->wg_waves, h->nslab_n);     // wg_waves row groups per workgroup
             N3Args na = n3_args(h);
-            na.xcd_remap = (h->xcd_remap > 0 && grid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
+            // (below ~512 row groups per rank there are too few workgroups per XCD for the locality to matter: neutral
+            //  at 16384..65536 particles, -5 % at 8192)
+            na.xcd_remap = (h->xcd_remap > 0 && grid.x >= 512 && grid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
             LJMD_HIP(h, launch_pair_n3(na, grid, h->wg_waves, h->stream));            // all pairs, or the NEAR ones
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y * h->wg_waves;                                      // one partial per wave
