@@ -329,6 +329,45 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
     }
 }
 
+// pair_n3 in two halves, for the batched reciprocal of column_tile_loop: the displacement and r^2 ...
+template <int NU>
+__device__ __forceinline__ void pair_geom(double xi, double yi, double zi, double xj, double yj, double zj, double L,
+                                          double invL, double sx, double sy, double sz, double &dx, double &dy,
+                                          double &dz, double &r2)
+{
+    constexpr bool gx = (NU < 8 && (NU & 1)) || NU == 24, gy = (NU < 8 && (NU & 2)) || NU == 25,
+                   gz = (NU < 8 && (NU & 4)) || NU == 26;
+    constexpr bool px = NU == 8 || (NU >= 16 && NU != 16 && NU != 24), py = NU == 8 || (NU >= 16 && NU != 17 && NU != 25),
+                   pz = NU == 8 || (NU >= 16 && NU != 18 && NU != 26);
+    dx = px ? (xi - xj) : gx ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
+    dy = py ? (yi - yj) : gy ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
+    dz = pz ? (zi - zj) : gz ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
+    r2 = fma(dz, dz, fma(dy, dy, dx * dx));
+}
+
+// ... and everything behind the reciprocal u = 1 / r^2
+template <bool INNER>
+__device__ __forceinline__ void pair_apply(double u, double dx, double dy, double dz, double r2, double rc2, double &ax,
+                                           double &ay, double &az, double &jx, double &jy, double &jz, double &s12,
+                                           double &s6)
+{
+    bool in = true;
+    if constexpr (!INNER) in = r2 < rc2;
+    if (in) {
+        const double u3 = u * u * u;
+        const double u6 = u3 * u3;
+        s12 += u6;
+        s6 += u3;
+        const double g = fma(2.0, u6, -u3) * u;
+        ax = fma(g, dx, ax);
+        ay = fma(g, dy, ay);
+        az = fma(g, dz, az);
+        jx = fma(-g, dx, jx);
+        jy = fma(-g, dy, jy);
+        jz = fma(-g, dz, jz);
+    }
+}
+
 // 64 rotation steps of one column tile against the wave's 4 row tiles (see pair_n3_kernel).
 // The column POSITIONS are read-only, so they do not have to travel through DPP: the tile is parked in LDS
 // twice in a row (entries i and i + 64), and at step s lane l reads entry (l + 64 - s) -- the particle that a
@@ -341,9 +380,20 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
 #ifndef LJMD_N3_UNROLL
 #define LJMD_N3_UNROLL 8
 #endif
+#ifndef LJMD_BATCH_RCP
+#define LJMD_BATCH_RCP 1       // one reciprocal per step for all row tiles of a lane (column_tile_loop<..., BATCH>)
+#endif
 constexpr int kLdsAxis = 2 * kTile;         // doubles per axis in the parked column tile
 
-template <int RT, int NU, bool MASKED, bool INNER>
+// BATCH (all RT row tiles active, no padding slot on either side): ONE reciprocal serves the RT pair evaluations of a
+// step.  v_rcp_f64 is a quarter-rate instruction (16 cycles against 4 for an fp64 FMA), so it and its Halley step are
+// a quarter of a pair evaluation; with p = r0^2 r1^2 r2^2 r3^2, y = 1/p (v_rcp_f64 + one Halley step, correctly rounded
+// as before) the four reciprocals are  1/r0^2 = r1^2 (y r2^2 r3^2), 1/r1^2 = r0^2 (y r2^2 r3^2), ... : 9 multiplications
+// and one reciprocal chain instead of four chains, 384 instead of 424 SIMD cycles per step.  Every r^2 of a full tile
+// pair is finite and far from under/overflow (r^2 <= 3 (L/2 + tile)^2, product of four <= 1e17 at L = 69), lanes
+// outside the cutoff compute a reciprocal they do not use.  Each 1/r^2 carries three roundings instead of one
+// (<= 1.5 ulp); the parity tests hold their bounds unchanged.
+template <int RT, int NU, bool MASKED, bool INNER, bool BATCH = false>
 __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const double (&yi)[RT],
                                                  const double (&zi)[RT], double (&ax)[RT],
                                                  double (&ay)[RT], double (&az)[RT],
@@ -351,6 +401,7 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const d
                                                  double L, double invL, double rc2, double sx, double sy, double sz,
                                                  double &jx, double &jy, double &jz, double &s12, double &s6)
 {
+    static_assert(!BATCH || (!MASKED && (RT == 2 || RT == 4)), "batched reciprocal: all row tiles, 2 or 4 of them");
 #if LJMD_LDS_POS
     // park = &lds[lane]: entry (lane + 64 - s), s = 0 is the lane's own particle (already in xj, yj, zj)
     double nx = xj, ny = yj, nz = zj;
@@ -360,11 +411,30 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const d
         nx = park[kTile - 1 - s];                       // next step's particle; the last prefetch (entry lane) is unused
         ny = park[kLdsAxis + kTile - 1 - s];
         nz = park[2 * kLdsAxis + kTile - 1 - s];
+        if constexpr (BATCH) {
+            double dx[RT], dy[RT], dz[RT], r2[RT], u[RT];
 #pragma unroll
-        for (int k = 0; k < RT; ++k)
-            if (!MASKED || ((mb >> k) & 1u))
-                pair_n3<false, NU, INNER>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
-                                          ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+            for (int k = 0; k < RT; ++k)
+                pair_geom<NU>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, sx, sy, sz, dx[k], dy[k], dz[k], r2[k]);
+            if constexpr (RT == 4) {
+                const double pab = r2[0] * r2[1], pcd = r2[2] * r2[3];
+                const double y = rcp_newton(pab * pcd);
+                const double rab = y * pcd, rcd = y * pab;
+                u[0] = r2[1] * rab; u[1] = r2[0] * rab; u[2] = r2[3] * rcd; u[3] = r2[2] * rcd;
+            } else {
+                const double y = rcp_newton(r2[0] * r2[1]);
+                u[0] = r2[1] * y; u[1] = r2[0] * y;
+            }
+#pragma unroll
+            for (int k = 0; k < RT; ++k)
+                pair_apply<INNER>(u[k], dx[k], dy[k], dz[k], r2[k], rc2, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+        } else {
+#pragma unroll
+            for (int k = 0; k < RT; ++k)
+                if (!MASKED || ((mb >> k) & 1u))
+                    pair_n3<false, NU, INNER>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
+                                              ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+        }
         jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
     }
 #else
@@ -442,7 +512,7 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
     // also: is every pair provably INSIDE the cutoff (no test needed)?  Column box from bbox[].
     double sx = 0.0, sy = 0.0, sz = 0.0;
     int nu;
-    bool inner;
+    bool inner, full;
     {
         const double *cbx = a.bbox + (size_t)c * kBoxStride;
         const double lo[3] = {glo[0] - cbx[3], glo[1] - cbx[4], glo[2] - cbx[5]};
@@ -454,7 +524,7 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
         const double fx = fmax(fabs(lo[0] - sx), fabs(hi[0] - sx)), fy = fmax(fabs(lo[1] - sy), fabs(hi[1] - sy)),
                      fz = fmax(fabs(lo[2] - sz), fabs(hi[2] - sz));
         // padding slots (NaN) must keep failing the cutoff test: INNER only for completely filled tiles
-        const bool full = group_full && ((c - (a.G == 1 ? 0 : c / a.TB) * a.TB) + 1) * kTile <= a.S;
+        full = group_full && ((c - (a.G == 1 ? 0 : c / a.TB) * a.TB) + 1) * kTile <= a.S;
         inner = __builtin_amdgcn_readfirstlane(
                     (int)(nu == 0 && full && (fx * fx + fy * fy + fz * fz) < a.rc2 * (1.0 - 1e-10))) != 0;
         if (nu & 1) sx = 0.0;
@@ -506,30 +576,36 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
     }
 #endif
 #define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
-    column_tile_loop<RT, NU_, MASKED_, INNER_>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
-                                           a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
-    const bool all4 = mb == ((1u << RT) - 1u);
+    column_tile_loop<RT, NU_, MASKED_, INNER_, false>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
+                                                  a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
+#define LJMD_LOOP_ALL(NU_, INNER_)                                                                           \
+    column_tile_loop<RT, NU_, false, INNER_, (RT == 2 || RT == 4) && LJMD_BATCH_RCP>(                              \
+        xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL, a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
+    // all row tiles active AND no padding slot anywhere in the tile pair: the unmasked loop with the batched
+    // reciprocal; otherwise the masked loop (correct for any mb; a NaN padding slot must not enter a product)
+    const bool all4 = mb == ((1u << RT) - 1u) && (full || !LJMD_BATCH_RCP);
 #ifdef LJMD_VARIANT_STATS
     if (lane == 0)          // measurement build only (tools/variant_stats.py): row tiles evaluated per class
         atomicAdd(&g_variant_stats[(nu & 31) * 2 + (inner ? 1 : 0)], (unsigned long long)__builtin_popcount(mb));
 #endif
-    if (nu == 8 && inner) { if (all4) LJMD_LOOP(8, false, true); else LJMD_LOOP(8, true, true); }
-    else if (nu == 8)     { if (all4) LJMD_LOOP(8, false, false); else LJMD_LOOP(8, true, false); }
-    else if (nu == 16 && inner) { if (all4) LJMD_LOOP(16, false, true); else LJMD_LOOP(16, true, true); }
-    else if (nu == 16)    { if (all4) LJMD_LOOP(16, false, false); else LJMD_LOOP(16, true, false); }
-    else if (nu == 17 && inner) { if (all4) LJMD_LOOP(17, false, true); else LJMD_LOOP(17, true, true); }
-    else if (nu == 17)    { if (all4) LJMD_LOOP(17, false, false); else LJMD_LOOP(17, true, false); }
-    else if (nu == 18 && inner) { if (all4) LJMD_LOOP(18, false, true); else LJMD_LOOP(18, true, true); }
-    else if (nu == 18)    { if (all4) LJMD_LOOP(18, false, false); else LJMD_LOOP(18, true, false); }
-    else if (nu == 0 && inner) { if (all4) LJMD_LOOP(0, false, true); else LJMD_LOOP(0, true, true); }
-    else if (nu == 0)     { if (all4) LJMD_LOOP(0, false, false); else LJMD_LOOP(0, true, false); }
-    else if (nu == 24)    { if (all4) LJMD_LOOP(24, false, false); else LJMD_LOOP(24, true, false); }
-    else if (nu == 25)    { if (all4) LJMD_LOOP(25, false, false); else LJMD_LOOP(25, true, false); }
-    else if (nu == 26)    { if (all4) LJMD_LOOP(26, false, false); else LJMD_LOOP(26, true, false); }
-    else if (nu == 1)     { if (all4) LJMD_LOOP(1, false, false); else LJMD_LOOP(1, true, false); }
-    else if (nu == 2)     { if (all4) LJMD_LOOP(2, false, false); else LJMD_LOOP(2, true, false); }
-    else if (nu == 4)     { if (all4) LJMD_LOOP(4, false, false); else LJMD_LOOP(4, true, false); }
-    else                  { if (all4) LJMD_LOOP(7, false, false); else LJMD_LOOP(7, true, false); }
+    if (nu == 8 && inner) { if (all4) LJMD_LOOP_ALL(8, true); else LJMD_LOOP(8, true, true); }
+    else if (nu == 8)     { if (all4) LJMD_LOOP_ALL(8, false); else LJMD_LOOP(8, true, false); }
+    else if (nu == 16 && inner) { if (all4) LJMD_LOOP_ALL(16, true); else LJMD_LOOP(16, true, true); }
+    else if (nu == 16)    { if (all4) LJMD_LOOP_ALL(16, false); else LJMD_LOOP(16, true, false); }
+    else if (nu == 17 && inner) { if (all4) LJMD_LOOP_ALL(17, true); else LJMD_LOOP(17, true, true); }
+    else if (nu == 17)    { if (all4) LJMD_LOOP_ALL(17, false); else LJMD_LOOP(17, true, false); }
+    else if (nu == 18 && inner) { if (all4) LJMD_LOOP_ALL(18, true); else LJMD_LOOP(18, true, true); }
+    else if (nu == 18)    { if (all4) LJMD_LOOP_ALL(18, false); else LJMD_LOOP(18, true, false); }
+    else if (nu == 0 && inner) { if (all4) LJMD_LOOP_ALL(0, true); else LJMD_LOOP(0, true, true); }
+    else if (nu == 0)     { if (all4) LJMD_LOOP_ALL(0, false); else LJMD_LOOP(0, true, false); }
+    else if (nu == 24)    { if (all4) LJMD_LOOP_ALL(24, false); else LJMD_LOOP(24, true, false); }
+    else if (nu == 25)    { if (all4) LJMD_LOOP_ALL(25, false); else LJMD_LOOP(25, true, false); }
+    else if (nu == 26)    { if (all4) LJMD_LOOP_ALL(26, false); else LJMD_LOOP(26, true, false); }
+    else if (nu == 1)     { if (all4) LJMD_LOOP_ALL(1, false); else LJMD_LOOP(1, true, false); }
+    else if (nu == 2)     { if (all4) LJMD_LOOP_ALL(2, false); else LJMD_LOOP(2, true, false); }
+    else if (nu == 4)     { if (all4) LJMD_LOOP_ALL(4, false); else LJMD_LOOP(4, true, false); }
+    else                  { if (all4) LJMD_LOOP_ALL(7, false); else LJMD_LOOP(7, true, false); }
+#undef LJMD_LOOP_ALL
 #undef LJMD_LOOP
 }
 
