@@ -1,4 +1,5 @@
 export TMPDIR=/tmp
+mkdir -p gpurun_out/wgpmc
 for W in 1 2 4; do
   LJMD_N3_WG_WAVES=$W rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/wgpmc/w$W -o run -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-liquid > /dev/null 2> gpurun_out/wgpmc/w$W.log
 done
