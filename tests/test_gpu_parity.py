@@ -820,3 +820,34 @@ def test_stateless_verlet_step_resident_fast_path(monkeypatch):
     print(f"stateless verlet_step loop, n = {n}: resident fast path {fast[2] / steps * 1e3:.2f} ms/call, "
           f"strict {strict[2] / steps * 1e3:.2f} ms/call")
     assert fast[2] < strict[2]
+
+
+@pytest.mark.parametrize("wg", ["2", "4"])
+def test_lds_combining_workgroups_equal_one_wave_per_workgroup(wg, monkeypatch, oracle):
+    """pair_n3_kernel<., 4, W>: W consecutive row groups per workgroup, column-side partial accelerations combined
+    in LDS (one slab block per workgroup and column tile).  Same pairs, different summation tree on the column side:
+    against the one-wave form to rounding, against the oracle within the usual bounds, and a 25-step trajectory
+    (crosses a re-sort); run-to-run bitwise.  n = 20000 leaves a partially filled last tile and row group."""
+    n = 20000
+    monkeypatch.setenv("LJMD_N3_ROW_TILES", "4")
+    p, r, v = synthetic.make_config(n, seed=17)
+    po = oracle.derive_params(p.n, p.box_length, p.dt, p.rc)
+    e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    ao = np.stack([ax, ay, az])
+    out = {}
+    for w in ("1", wg, wg):
+        monkeypatch.setenv("LJMD_N3_WG_WAVES", w)
+        with Engine(p) as eng:
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            sc0 = eng.compute_forces()
+            a0 = np.stack(eng.get_state(("a",))["a"])
+            sc = np.stack(eng.verlet_steps(25), axis=1)
+        out.setdefault(w, []).append((np.array(sc0), a0, sc))
+    one, (wa, wb) = out["1"][0], out[wg]
+    assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and np.array_equal(wa[2], wb[2])   # deterministic
+    assert np.max(np.abs(wa[0] - one[0]) / np.abs(one[0])) < 1e-13
+    assert np.abs(wa[1] - one[1]).max() < 1e-12 * np.abs(one[1]).max()
+    assert np.max(np.abs(wa[2] - one[2]) / np.abs(one[2])) < 1e-11
+    for mine, ref in zip(wa[0], (e_o, d_o, dd_o)):
+        assert rel(mine, ref) <= REL_SCALAR
+    assert np.abs(wa[1] - ao).max() <= REL_ACCEL * np.abs(ao).max()
