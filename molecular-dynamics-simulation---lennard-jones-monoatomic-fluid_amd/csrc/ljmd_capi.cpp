@@ -287,6 +287,7 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
                 fa.slab_j = h->d_slab_j2;
                 fa.flag_j = h->d_flag_j2;
                 fa.Q = h->Q2;
+                fa.xcd_remap = (h->xcd_remap > 0 && fgrid.x >= 512 && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
                 LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, h->stream));
                 nslab *= 2;

@@ -894,7 +894,14 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
 __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
 {
     const int lane = threadIdx.x;                              // one wave per workgroup (see pair_n3_kernel)
-    const int Al = blockIdx.x;
+    unsigned bx = blockIdx.x, by = blockIdx.y;                 // XCD-aware work mapping, as in pair_n3_kernel
+    if (a.xcd_remap) {
+        const unsigned id = blockIdx.y * gridDim.x + blockIdx.x, per = gridDim.x >> 3, C = (unsigned)a.xcd_remap;
+        const unsigned xcd = id & 7u, slot = id >> 3, s = slot % per;
+        by = slot / per;
+        bx = ((s / C) * 8u + xcd) * C + s % C;
+    }
+    const int Al = (int)bx;
     const bool active = Al < a.NGo;
     const int A = a.rank * a.NGo + Al;
     const size_t P = a.P;
@@ -927,7 +934,7 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
         ax[k] = ay[k] = az[k] = 0.0;
     }
 
-    const int d0 = blockIdx.y * a.dchunk;
+    const int d0 = (int)by * a.dchunk;
     const int d1 = active ? min(d0 + a.dchunk, a.Dmax + 1) : d0;
     for (int d = d0; d < d1; ++d) {
         int B = A + d;
@@ -1001,7 +1008,7 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
     }
 
     if (active) {
-        double *si = a.slab_i + (size_t)blockIdx.y * 3 * P;
+        double *si = a.slab_i + (size_t)by * 3 * P;
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k) {
             const size_t slot = (size_t)(kRowTiles * Al + k) * kTile + lane;
@@ -1012,7 +1019,7 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
     }
     const double r12 = wave_sum(s12), r6 = wave_sum(s6);
     if (lane == 0) {
-        double *w = a.wg_part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        double *w = a.wg_part + 2 * ((size_t)by * gridDim.x + bx);
         w[0] = r12;
         w[1] = r6;
     }
