@@ -675,8 +675,8 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         int rt = env_int("LJMD_N3_ROW_TILES", 0);
         if (mixed_mode) rt = kRowTiles;                       // the fp32 far kernel is built for 4
         if (rt != 1 && rt != 2 && rt != kRowTiles) {
-            // measured (tools/sweep_small_n.sh, profiles/r01_sweep_pair_variants.txt): 4 wins from n = 131072 up,
-            // 2 for 16384..65536, 1 below
+            // measured (profiles/r02_row_tiles_sweep.txt, with the batched reciprocal): 4 wins from n = 65536 up,
+            // 2 for 16384..32768, 1 below
             auto items = [&](int cand) { const long ngo = h->TB / cand; return ngo * ((long)h->G * ngo / 2 + 1); };
             rt = items(kRowTiles) >= kN3ItemsFor4 ? kRowTiles : items(2) >= kN3ItemsFor2 ? 2 : 1;
         }

@@ -29,7 +29,7 @@ extern thread_local std::string g_last_error;
 constexpr unsigned kRingCap = 4096;     // per-step partial records kept on the device
 constexpr int kTargetWorkgroups = 2048; // >> 256 CUs (8 per CU) for the pair kernels
 constexpr int kMixedMinN = 16384;       // smallest system the mixed-precision mode accepts
-constexpr long kN3ItemsFor4 = 40000;    // Newton-3 work items (row groups x offsets) a rank needs before 4 ...
+constexpr long kN3ItemsFor4 = 30000;    // Newton-3 work items (row groups x offsets) a rank needs before 4 ...
 constexpr long kN3ItemsFor2 = 6144;     // ... or 2 tiles per row group pay off
 constexpr int kMaxProfiledLaunches = 4096;
 constexpr int kEventsPerLaunch = 5;
