@@ -851,3 +851,36 @@ def test_lds_combining_workgroups_equal_one_wave_per_workgroup(wg, monkeypatch, 
     for mine, ref in zip(wa[0], (e_o, d_o, dd_o)):
         assert rel(mine, ref) <= 1e-12            # 2e8 terms per sum on both sides (as in the full-size parity test)
     assert np.abs(wa[1] - ao).max() <= REL_ACCEL * np.abs(ao).max()
+
+
+def test_full_size_invariances_permutation_translation_reflection():
+    """Size-independent properties of the force routine at the bench size (n = 262144), where no CPU run of the
+    reference exists beyond the single oracle comparison above: the result must not depend on the ORDER of the
+    particles (other tiles, other work items, other summation trees: agreement to rounding), on a rigid TRANSLATION of
+    the periodic system (other images, other tile boxes), or on a REFLECTION x -> L - x (forces change sign in x)."""
+    n = 262144
+    p, r, v = synthetic.make_config(n, seed=41)
+    L = p.box_length
+    rng = np.random.Generator(np.random.PCG64(99))
+    perm = rng.permutation(n)
+    shift = np.array([0.37 * L, -1.21 * L, 0.5 * L])
+    r_shift = np.mod(r + shift[:, None], L)
+    r_refl = r.copy()
+    r_refl[0] = np.mod(L - r[0], L)
+    res = []
+    with Engine(p) as eng:
+        for pos in (r, np.ascontiguousarray(r[:, perm]), r_shift, r_refl):
+            eng.set_state(pos[0], pos[1], pos[2], v[0], v[1], v[2])
+            sc = np.array(eng.compute_forces())
+            res.append((sc, np.stack(eng.get_state(("a",))["a"])))
+    (s0, a0), (s1, a1), (s2, a2), (s3, a3) = res
+    amax = np.abs(a0).max()
+    for name, s in (("permutation", s1), ("translation", s2), ("reflection", s3)):
+        assert np.max(np.abs(s - s0) / np.abs(s0)) <= 1e-12, (name, s, s0)
+    assert np.abs(a1 - a0[:, perm]).max() <= 1e-12 * amax
+    # a translated / reflected coordinate differs from the original in its last bits (mod, L - x): the pair distances
+    # change by ~1e-14 relative, the r^-13 forces by ~1e-13 per close pair
+    assert np.abs(a2 - a0).max() <= 1e-10 * amax
+    a3[0] *= -1.0
+    assert np.abs(a3 - a0).max() <= 1e-10 * amax
+    assert np.abs(a0.sum(axis=1)).max() <= 1e-9 * amax                      # Newton's third law, all pairs
