@@ -586,7 +586,10 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
     const bool all4 = mb == ((1u << RT) - 1u) && (full || !LJMD_BATCH_RCP);
 #ifdef LJMD_VARIANT_STATS
     if (lane == 0)          // measurement build only (tools/variant_stats.py): row tiles evaluated per class
+    {
         atomicAdd(&g_variant_stats[(nu & 31) * 2 + (inner ? 1 : 0)], (unsigned long long)__builtin_popcount(mb));
+        atomicAdd(&g_variant_stats[56 + __builtin_popcount(mb)], 1ull);      // column-tile passes by active row tiles
+    }
 #endif
     if (nu == 8 && inner) { if (all4) LJMD_LOOP_ALL(8, true); else LJMD_LOOP(8, true, true); }
     else if (nu == 8)     { if (all4) LJMD_LOOP_ALL(8, false); else LJMD_LOOP(8, true, false); }

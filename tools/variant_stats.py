@@ -29,10 +29,16 @@ with Engine(p) as eng:
         eng.compute_forces()
         eng.synchronize()
         lib.ljmd_debug_variant_stats(buf, 1)
-        tot = sum(buf)
+        by_rows = [buf[56 + k] for k in range(5)]
+        tot = sum(buf[k] for k in range(56))
         pairs_all = n * (n - 1) / 2
         print(f"== {label}: {tot} (row tile, column tile) passes = {tot * 4096 / pairs_all:.3f} of all unordered pairs "
               f"(diagonal-tile passes are not counted)")
+        rows_tot = sum(k * by_rows[k] for k in range(5))
+        if rows_tot:
+            print("  column-tile passes by number of active row tiles (1..4): "
+                  + ", ".join(f"{k}: {100.0 * by_rows[k] / sum(by_rows):.1f} %" for k in range(1, 5))
+                  + f"; share of the pair evaluations in passes with all four active: {100.0 * 4 * by_rows[4] / rows_tot:.1f} %")
         for nu, name in names.items():
             a, b = buf[nu * 2], buf[nu * 2 + 1]
             if a + b:
