@@ -73,6 +73,7 @@ N3Args n3_args(ljmd_t *h)
     a.pos = h->d_pos;
     a.mask = h->d_mask;
     a.bbox = h->d_bbox;
+    a.desc = h->d_desc;
     a.slab_i = h->d_slab;
     a.slab_j = h->d_slab_j;
     a.flag_j = h->d_flag_j;
@@ -267,6 +268,8 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (!h->boxes_valid) LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
         h->boxes_valid = false;                    // good for this evaluation only
         LJMD_HIP(h, launch_tile_mask(ga, h->stream));
+        if (h->use_n3)      // pass descriptors of the fp64 Newton-3 kernel (from its own mask: the NEAR pairs in the mixed mode)
+            LJMD_HIP(h, launch_tile_class(ga, h->invL, h->rc2, h->S, h->NGo, h->d_desc, h->stream));
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
             const dim3 grid((h->NGo + h->wg_waves - 1) / h->wg_waves, h->nslab_n);     // wg_waves row groups per workgroup
@@ -462,7 +465,8 @@ void release(ljmd_t *h)
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv, h->d_fall,
-                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket};
+                   h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket,
+                   h->d_desc};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -744,6 +748,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
             LJMD_HIP(h, hipMalloc(&h->d_slab_j, n_blk * 3 * kTile * sizeof(double)));
             LJMD_HIP(h, hipMalloc(&h->d_flag_j, n_blk));
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, n_blk, h->stream));
+            LJMD_HIP(h, hipMalloc(&h->d_desc, (size_t)h->NGo * h->T * sizeof(unsigned)));
         }
         if (mixed) {
             LJMD_HIP(h, hipMalloc(&h->d_mask_far, (size_t)h->TB * h->W * sizeof(uint64_t)));

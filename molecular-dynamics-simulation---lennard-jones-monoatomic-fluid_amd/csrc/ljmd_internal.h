@@ -52,7 +52,8 @@ struct PairArgs {
 struct N3Args {
     const double *pos;      // exchange buffer
     const uint64_t *mask;   // [TB rows][W] tile-pair mask of the owned row tiles
-    const double *bbox;     // [T][kBoxStride] exact tile bounding boxes (image classification)
+    const double *bbox;     // [T][kBoxStride] exact tile bounding boxes (fp32 far kernel: image classification)
+    const unsigned *desc;   // [NGo][T] pass descriptors of tile_class_kernel (row-tile mask bits, loop variant, images)
     double *slab_i;         // [nchunk][3][P] partial accelerations of the owned rows (row side)
     double *slab_j;         // [ceil(NGo/WG)][Q][3][64] column-side partial accelerations: one block per (workgroup of WG
                             // consecutive row groups, column tile), Q = (Dmax + WG) * RT column tiles per workgroup
@@ -149,6 +150,7 @@ hipError_t launch_finalize(const FinalizeArgs &a, double *fold_scratch /* [2 * k
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s);
+hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc, hipStream_t s);
 
 // ljmd_sort.hip
 size_t sort_temp_bytes(int count);

@@ -484,14 +484,13 @@ __device__ __forceinline__ void wave_lds_sync()
     }
 }
 
-// One column tile against the wave's RT row tiles: image classification, then the 64 rotation steps in the loop
-// variant that fits.  PREFETCHED = the tile's positions already lie in `parked` (LDS-DMA issued one tile earlier);
-// otherwise they are loaded here and parked.  after_classification() is called between the classification (whose
-// loads are consumed by then) and the rotation loop (which touches LDS only): the place to issue the NEXT tile's
-// LDS-DMA so that it overlaps the whole loop and no later s_waitcnt vmcnt of this tile has to wait for it.
+// One column tile against the wave's RT row tiles: the 64 rotation steps in the loop variant the pass descriptor names.  PREFETCHED = the tile's positions already lie in `parked` (LDS-DMA issued one tile earlier);
+// otherwise they are loaded here and parked.  after_classification() is called just before the rotation loop (which
+// touches LDS only): the place to issue the NEXT tile's LDS-DMA so that it overlaps the whole loop and no later
+// s_waitcnt vmcnt of this tile has to wait for it.
 template <int RT, int W, bool PREFETCHED, typename AFTER>
-__device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, int d, int l, unsigned mb, bool group_full,
-                                             const double (&glo)[3], const double (&ghi)[3], const double (&xi)[RT],
+__device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, int d, int l, unsigned mb, unsigned desc,
+                                             const double (&xi)[RT],
                                              const double (&yi)[RT], const double (&zi)[RT], double (&ax)[RT],
                                              double (&ay)[RT], double (&az)[RT], double *parked, AFTER &&after_classification,
                                              double &jx, double &jy, double &jz, double &s12, double &s6)
@@ -508,38 +507,12 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
         xj = cb[0]; yj = cb[P]; zj = cb[2 * P];
     }
 
-    // per axis: same periodic image for every pair of (row group, column tile)?  If so for all three,
-    // also: is every pair provably INSIDE the cutoff (no test needed)?  Column box from bbox[].
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    int nu;
-    bool inner, full;
-    {
-        const double *cbx = a.bbox + (size_t)c * kBoxStride;
-        const double lo[3] = {glo[0] - cbx[3], glo[1] - cbx[4], glo[2] - cbx[5]};
-        const double hi[3] = {ghi[0] - cbx[0], ghi[1] - cbx[1], ghi[2] - cbx[2]};
-        const bool ux = uniform_image(lo[0], hi[0], a.L, a.invL, sx);
-        const bool uy = uniform_image(lo[1], hi[1], a.L, a.invL, sy);
-        const bool uz = uniform_image(lo[2], hi[2], a.L, a.invL, sz);
-        nu = __builtin_amdgcn_readfirstlane((ux ? 0 : 1) | (uy ? 0 : 2) | (uz ? 0 : 4));
-        const double fx = fmax(fabs(lo[0] - sx), fabs(hi[0] - sx)), fy = fmax(fabs(lo[1] - sy), fabs(hi[1] - sy)),
-                     fz = fmax(fabs(lo[2] - sz), fabs(hi[2] - sz));
-        // padding slots (NaN) must keep failing the cutoff test: INNER only for completely filled tiles
-        full = group_full && ((c - (a.G == 1 ? 0 : c / a.TB) * a.TB) + 1) * kTile <= a.S;
-        inner = __builtin_amdgcn_readfirstlane(
-                    (int)(nu == 0 && full && (fx * fx + fy * fy + fz * fz) < a.rc2 * (1.0 - 1e-10))) != 0;
-        if (nu & 1) sx = 0.0;
-        if (nu & 2) sy = 0.0;
-        if (nu & 4) sz = 0.0;
-        if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
-        if (nu == 1 && sy == 0.0 && sz == 0.0) nu = 24;          // one general axis, no image on the others
-        else if (nu == 2 && sx == 0.0 && sz == 0.0) nu = 25;
-        else if (nu == 4 && sx == 0.0 && sy == 0.0) nu = 26;
-        nu = __builtin_amdgcn_readfirstlane(nu);
-        if (nu == 0) {
-            const int nz = __builtin_amdgcn_readfirstlane((sx != 0.0 ? 1 : 0) | (sy != 0.0 ? 2 : 0) | (sz != 0.0 ? 4 : 0));
-            nu = nz == 0 ? 8 : nz == 1 ? 16 : nz == 2 ? 17 : nz == 4 ? 18 : 0;   // none / one axis / several
-        }
-    }
+    // the pass descriptor (tile_class_kernel): loop variant, INNER, FULL and the common image per axis
+    const int nu = (int)((desc >> 4) & 31u);
+    const bool inner = ((desc >> 9) & 1u) != 0, full = ((desc >> 10) & 1u) != 0;
+    const double sx = (double)((int)((desc >> 11) & 7u) - 2) * a.L;     // n L, exact for |n| <= 2
+    const double sy = (double)((int)((desc >> 14) & 7u) - 2) * a.L;
+    const double sz = (double)((int)((desc >> 17) & 7u) - 2) * a.L;
     after_classification();
 
     if (d == 0 && ((mb >> l) & 1u)) {
@@ -676,23 +649,6 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         ax[k] = ay[k] = az[k] = 0.0;
     }
 
-    // bounding box of the whole row group (256 particles), wave-uniform, for the image classification
-    double glo[3], ghi[3];
-    {
-        double mx[3] = {xi[0], yi[0], zi[0]}, Mx[3] = {xi[0], yi[0], zi[0]};
-#pragma unroll
-        for (int k = 1; k < RT; ++k) {
-            mx[0] = fmin(mx[0], xi[k]); mx[1] = fmin(mx[1], yi[k]); mx[2] = fmin(mx[2], zi[k]);
-            Mx[0] = fmax(Mx[0], xi[k]); Mx[1] = fmax(Mx[1], yi[k]); Mx[2] = fmax(Mx[2], zi[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            glo[k] = __shfl(wave_min(mx[k]), 0, 64);
-            ghi[k] = __shfl(wave_max(Mx[k]), 0, 64);
-        }
-    }
-
-    const bool group_full = (RT * Al + RT) * kTile <= a.S;   // no padding slot among the 256 rows
     // e = offset of the column group from the workgroup's FIRST row group; wave w is at its own offset d = e - w.
     // Every wave of the workgroup runs the same e and l trip counts (one barrier per column tile when W > 1).
     const int e0 = (int)by * a.dchunk;
@@ -700,7 +656,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
 
     // tile t = (e - e0) * RT + l of this work item: its column tile c, offset d, slab block, and the mask bits of the
     // wave's RT row tiles (0 = nothing to do: not owned, or every row tile proven outside the cutoff)
-    auto tile_of = [&](int t, int &c, int &d, int &l, size_t &blk) -> unsigned {
+    auto tile_of = [&](int t, int &c, int &d, int &l, size_t &blk, unsigned &desc) -> unsigned {
         const int e = e0 + t / RT;
         l = t - (t / RT) * RT;
         d = e - wv;
@@ -711,25 +667,23 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         c = RT * B + l;                                 // column tile (global)
         blk = (size_t)bx * a.Q + (size_t)e * RT + l;
         unsigned mb = 0;
+        desc = 0;
         if (owned) {
-#pragma unroll
-            for (int k = 0; k < RT; ++k) {
-                const uint64_t w = a.mask[(size_t)(RT * Al + k) * a.W + (c >> 6)];
-                mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
-            }
+            // wave-uniform by construction: keep it in SGPRs so that the per-row-tile tests are scalar branches
+            desc = (unsigned)__builtin_amdgcn_readfirstlane((int)a.desc[(size_t)Al * a.T + c]);
+            mb = desc & 15u;
             if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
         }
-        // wave-uniform by construction: keep it in an SGPR so that the per-row-tile tests are scalar branches
-        return (unsigned)__builtin_amdgcn_readfirstlane((int)mb);
+        return mb;
     };
     const int nt = (e1 - e0) * RT;
 
     if constexpr (kPrefetch) {
         // one wave per workgroup: walk the KEPT tiles only, the next kept tile's positions in flight (LDS-DMA into the
         // other parking buffer) while the current tile's 64 rotation steps run
-        auto next_kept = [&](int t, int &c, int &d, int &l, size_t &blk, unsigned &mb) -> int {
+        auto next_kept = [&](int t, int &c, int &d, int &l, size_t &blk, unsigned &mb, unsigned &desc) -> int {
             for (; t < nt; ++t) {
-                mb = tile_of(t, c, d, l, blk);
+                mb = tile_of(t, c, d, l, blk, desc);
                 if (mb) break;
                 if (lane == 0) a.flag_j[blk] = 0;
             }
@@ -737,18 +691,18 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         };
         int c, d, l, cn = 0, dn = 0, ln = 0;
         size_t blk, blkn = 0;
-        unsigned mb = 0, mbn = 0;
-        int t = next_kept(0, c, d, l, blk, mb);
+        unsigned mb = 0, mbn = 0, desc = 0, descn = 0;
+        int t = next_kept(0, c, d, l, blk, mb, desc);
         int cur = 0;
         if (t < nt) tile_to_lds_async(a, lane, c, parked_all[0][0]);
         while (t < nt) {
-            const int tn = next_kept(t + 1, cn, dn, ln, blkn, mbn);
+            const int tn = next_kept(t + 1, cn, dn, ln, blkn, mbn, descn);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t has landed (issued one tile ago)
             __builtin_amdgcn_wave_barrier();
             double jx = 0.0, jy = 0.0, jz = 0.0;
             double *pk_cur = cur ? parked_all[0][1] : parked_all[0][0];
             double *pk_next = cur ? parked_all[0][0] : parked_all[0][1];
-            n3_tile_pass<RT, W, true>(a, lane, c, d, l, mb, group_full, glo, ghi, xi, yi, zi, ax, ay, az, pk_cur,
+            n3_tile_pass<RT, W, true>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, pk_cur,
                                       [&]() { if (tn < nt) tile_to_lds_async(a, lane, cn, pk_next); },
                                       jx, jy, jz, s12, s6);
             double *o = a.slab_j + blk * (3 * kTile) + lane;
@@ -756,7 +710,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             o[kTile] = jy;
             o[2 * kTile] = jz;
             if (lane == 0) a.flag_j[blk] = 1;
-            t = tn; c = cn; d = dn; l = ln; blk = blkn; mb = mbn;
+            t = tn; c = cn; d = dn; l = ln; blk = blkn; mb = mbn; desc = descn;
             cur ^= 1;
         }
     } else {
@@ -765,11 +719,12 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         for (int t = 0; t < nt; ++t) {
             int c, d, l;
             size_t blk;
-            const unsigned mb = tile_of(t, c, d, l, blk);
+            unsigned desc;
+            const unsigned mb = tile_of(t, c, d, l, blk, desc);
             const bool have = mb != 0;
             double jx = 0.0, jy = 0.0, jz = 0.0;
             if (have)
-                n3_tile_pass<RT, W, false>(a, lane, c, d, l, mb, group_full, glo, ghi, xi, yi, zi, ax, ay, az, parked,
+                n3_tile_pass<RT, W, false>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, parked,
                                            []() {}, jx, jy, jz, s12, s6);
             if constexpr (W == 1) {
                 if (have) {
@@ -1100,6 +1055,68 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
     }
     const uint64_t word = __ballot(keep);
     if (lane == 0) a.mask[(size_t)Il * a.W + w] = word;
+}
+
+// ---------------------------------------------------------------------------
+// Geometry pre-pass 3 (Newton-3 kernel): one 32-bit descriptor per (owned row group, column tile) -- everything the
+// pair kernel needs to know about a pass, computed ONCE by one lane here instead of redundantly by the 64 lanes of the
+// wave in the pair kernel's prologue (~120 fp64 VALU instructions per pass there, 2 % of the kernel):
+//   bits  0..3   row tiles of the group whose mask bit for this column tile is set (tile_mask_kernel)
+//   bits  4..8   loop variant nu (pair_n3): image class of the (row group, column tile) pair
+//   bit   9      INNER: every pair provably inside the cutoff
+//   bit   10     FULL: no padding slot in the row group or the column tile
+//   bits 11..19  common image per axis, n + 2 in 3 bits each (shift = n L)
+// Same expressions as the former in-kernel classification; the row group's box is the union of its tiles' exact
+// boxes (= min / max over its 256 particles).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, double invL, double rc2, int S, unsigned *desc)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;           // column tile (global)
+    const int Al = blockIdx.y;                                 // owned row group
+    if (c >= a.T) return;
+    const int RT = a.RT;
+    double glo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+    double ghi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+    unsigned mb = 0;
+    for (int k = 0; k < RT; ++k) {
+        const int tl = RT * Al + k;
+        const double *bb = a.bbox + (size_t)(a.rank * a.TB + tl) * kBoxStride;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            glo[q] = fmin(glo[q], bb[q]);                      // fmin / fmax ignore the NaN of an all-padding tile
+            ghi[q] = fmax(ghi[q], bb[3 + q]);
+        }
+        const uint64_t w = a.mask[(size_t)tl * a.W + (c >> 6)];
+        mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
+    }
+    const double *cbx = a.bbox + (size_t)c * kBoxStride;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    const double lo[3] = {glo[0] - cbx[3], glo[1] - cbx[4], glo[2] - cbx[5]};
+    const double hi[3] = {ghi[0] - cbx[0], ghi[1] - cbx[1], ghi[2] - cbx[2]};
+    const bool ux = uniform_image(lo[0], hi[0], a.L, invL, sx);
+    const bool uy = uniform_image(lo[1], hi[1], a.L, invL, sy);
+    const bool uz = uniform_image(lo[2], hi[2], a.L, invL, sz);
+    int nu = (ux ? 0 : 1) | (uy ? 0 : 2) | (uz ? 0 : 4);
+    const double fx = fmax(fabs(lo[0] - sx), fabs(hi[0] - sx)), fy = fmax(fabs(lo[1] - sy), fabs(hi[1] - sy)),
+                 fz = fmax(fabs(lo[2] - sz), fabs(hi[2] - sz));
+    const bool group_full = (RT * Al + RT) * kTile <= S;
+    const bool full = group_full && ((c - (a.G == 1 ? 0 : c / a.TB) * a.TB) + 1) * kTile <= S;
+    const bool inner = nu == 0 && full && (fx * fx + fy * fy + fz * fz) < rc2 * (1.0 - 1e-10);
+    if (nu & 1) sx = 0.0;
+    if (nu & 2) sy = 0.0;
+    if (nu & 4) sz = 0.0;
+    if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
+    if (nu == 1 && sy == 0.0 && sz == 0.0) nu = 24;          // one general axis, no image on the others
+    else if (nu == 2 && sx == 0.0 && sz == 0.0) nu = 25;
+    else if (nu == 4 && sx == 0.0 && sy == 0.0) nu = 26;
+    if (nu == 0) {
+        const int nz = (sx != 0.0 ? 1 : 0) | (sy != 0.0 ? 2 : 0) | (sz != 0.0 ? 4 : 0);
+        nu = nz == 0 ? 8 : nz == 1 ? 16 : nz == 2 ? 17 : nz == 4 ? 18 : 0;   // none / one axis / several
+    }
+    // shift = n L with |n| <= 2 (uniform_image): recover n exactly
+    const int nx = (int)__builtin_rint(sx * invL), ny = (int)__builtin_rint(sy * invL), nzs = (int)__builtin_rint(sz * invL);
+    desc[(size_t)Al * a.T + c] = mb | ((unsigned)nu << 4) | ((unsigned)inner << 9) | ((unsigned)full << 10) |
+                                 ((unsigned)(nx + 2) << 11) | ((unsigned)(ny + 2) << 14) | ((unsigned)(nzs + 2) << 17);
 }
 
 // ---------------------------------------------------------------------------
@@ -1479,6 +1496,12 @@ hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s)
 hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(tile_mask_kernel, dim3(a.W, (a.TB + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc, hipStream_t s)
+{
+    hipLaunchKernelGGL(tile_class_kernel, dim3((a.T + kBlock - 1) / kBlock, NGo), dim3(kBlock), 0, s, a, invL, rc2, S, desc);
     return hipGetLastError();
 }
 
