@@ -268,8 +268,14 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (!h->boxes_valid) LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
         h->boxes_valid = false;                    // good for this evaluation only
         LJMD_HIP(h, launch_tile_mask(ga, h->stream));
-        if (h->use_n3)      // pass descriptors of the fp64 Newton-3 kernel (from its own mask: the NEAR pairs in the mixed mode)
+        if (h->use_n3) {    // pass descriptors of the fp64 Newton-3 kernel (from its own mask: the NEAR pairs in the mixed mode)
             LJMD_HIP(h, launch_tile_class(ga, h->invL, h->rc2, h->S, h->NGo, h->d_desc, h->stream));
+            if (h->mode == LJMD_PRECISION_FP32_FORCE) {       // ... and of the fp32 far kernel, from the FAR mask
+                GeometryArgs gf = ga;
+                gf.mask = h->d_mask_far;
+                LJMD_HIP(h, launch_tile_class(gf, h->invL, h->rc2, h->S, h->NGo, h->d_desc_far, h->stream));
+            }
+        }
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
             const dim3 grid((h->NGo + h->wg_waves - 1) / h->wg_waves, h->nslab_n);     // wg_waves row groups per workgroup
@@ -289,6 +295,7 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
                 fa.slab_i = h->d_slab + (size_t)h->nslab_n * 3 * h->P;
                 fa.slab_j = h->d_slab_j2;
                 fa.flag_j = h->d_flag_j2;
+                fa.desc = h->d_desc_far;
                 fa.Q = h->Q2;
                 fa.xcd_remap = (h->xcd_remap > 0 && fgrid.x >= 512 && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
@@ -466,7 +473,7 @@ void release(ljmd_t *h)
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv, h->d_fall,
                    h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket,
-                   h->d_desc};
+                   h->d_desc, h->d_desc_far};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -752,6 +759,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         }
         if (mixed) {
             LJMD_HIP(h, hipMalloc(&h->d_mask_far, (size_t)h->TB * h->W * sizeof(uint64_t)));
+            LJMD_HIP(h, hipMalloc(&h->d_desc_far, (size_t)h->NGo * h->T * sizeof(unsigned)));
             LJMD_HIP(h, hipMalloc(&h->d_slab_j2, (size_t)h->NGo * h->Q2 * 3 * kTile * sizeof(double)));
             LJMD_HIP(h, hipMalloc(&h->d_flag_j2, (size_t)h->NGo * h->Q2));
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j2, 0, (size_t)h->NGo * h->Q2, h->stream));

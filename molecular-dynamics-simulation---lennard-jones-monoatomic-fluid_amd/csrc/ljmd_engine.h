@@ -97,6 +97,7 @@ struct ljmd {
     double *d_bbox = nullptr;     // [T][kBoxStride]
     uint64_t *d_mask = nullptr;   // [TB][W]
     unsigned *d_desc = nullptr;   // [NGo][T] pass descriptors of the Newton-3 kernel (tile_class_kernel)
+    unsigned *d_desc_far = nullptr;   // same for the fp32 far kernel of the mixed mode (from mask_far)
     // sorting scratch
     unsigned *d_keys = nullptr, *d_keys2 = nullptr;
     int *d_idx = nullptr, *d_idx2 = nullptr, *d_perm = nullptr, *d_perm2 = nullptr;

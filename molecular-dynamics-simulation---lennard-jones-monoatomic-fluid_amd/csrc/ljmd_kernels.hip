@@ -870,8 +870,6 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
     double cx[kRowTiles], cy[kRowTiles], cz[kRowTiles];
     float ox[kRowTiles], oy[kRowTiles], oz[kRowTiles];
     double ax[kRowTiles], ay[kRowTiles], az[kRowTiles];
-    double glo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
-    double ghi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
     double s12 = 0.0, s6 = 0.0;
 #pragma unroll
     for (int k = 0; k < kRowTiles; ++k) {
@@ -880,11 +878,6 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
         cx[k] = 0.5 * (bb[0] + bb[3]);
         cy[k] = 0.5 * (bb[1] + bb[4]);
         cz[k] = 0.5 * (bb[2] + bb[5]);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            glo[q] = fmin(glo[q], bb[q]);
-            ghi[q] = fmax(ghi[q], bb[3 + q]);
-        }
         const size_t slot = (size_t)tl * kTile + lane;
         ox[k] = (float)(own[slot] - cx[k]);
         oy[k] = (float)(own[P + slot] - cy[k]);
@@ -901,31 +894,24 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
         for (int l = 0; l < kRowTiles; ++l) {
             const int c = kRowTiles * B + l;
             const size_t blk = (size_t)Al * a.Q + (size_t)d * kRowTiles + l;
-            unsigned mb = 0;
-            if (own_pair && d != 0) {                      // the diagonal group is always a NEAR (fp64) pair
-#pragma unroll
-                for (int k = 0; k < kRowTiles; ++k) {
-                    const uint64_t w = a.mask[(size_t)(kRowTiles * Al + k) * a.W + (c >> 6)];
-                    mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
-                }
-            }
+            unsigned desc = 0;
+            if (own_pair && d != 0)                        // the diagonal group is always a NEAR (fp64) pair
+                desc = (unsigned)__builtin_amdgcn_readfirstlane((int)a.desc[(size_t)Al * a.T + c]);   // built from mask_far
+            const unsigned mb = desc & 15u;
             if (mb == 0) {
                 if (lane == 0) a.flag_j[blk] = 0;
                 continue;
             }
             const double *cbx = a.bbox + (size_t)c * kBoxStride;
             const double ccx = 0.5 * (cbx[0] + cbx[3]), ccy = 0.5 * (cbx[1] + cbx[4]), ccz = 0.5 * (cbx[2] + cbx[5]);
-            double sx = 0.0, sy = 0.0, sz = 0.0;
-            const bool ux = uniform_image(glo[0] - cbx[3], ghi[0] - cbx[0], a.L, a.invL, sx);
-            const bool uy = uniform_image(glo[1] - cbx[4], ghi[1] - cbx[1], a.L, a.invL, sy);
-            const bool uz = uniform_image(glo[2] - cbx[5], ghi[2] - cbx[2], a.L, a.invL, sz);
-            // per axis: common image (shift folded below) or general; two or more general axes -> all general
-            int gen = __builtin_amdgcn_readfirstlane((ux ? 0 : 1) | (uy ? 0 : 2) | (uz ? 0 : 4));
-            if (gen & 1) sx = 0.0;
-            if (gen & 2) sy = 0.0;
-            if (gen & 4) sz = 0.0;
-            if (gen != 0 && gen != 1 && gen != 2 && gen != 4) gen = 7;   // (a folded shift on an axis that is then
-                                                                          //  also treated generally is harmless)
+            // image class from the pass descriptor (tile_class_kernel): per axis common image (its shift folded into the
+            // row offsets below) or general; two or more general axes -> all general (a folded shift on an axis that is
+            // then also treated generally is harmless)
+            const int nu = (int)((desc >> 4) & 31u);
+            const int gen = (nu == 24 || nu == 1) ? 1 : (nu == 25 || nu == 2) ? 2 : (nu == 26 || nu == 4) ? 4 : nu == 7 ? 7 : 0;
+            const double sx = (double)((int)((desc >> 11) & 7u) - 2) * a.L;
+            const double sy = (double)((int)((desc >> 14) & 7u) - 2) * a.L;
+            const double sz = (double)((int)((desc >> 17) & 7u) - 2) * a.L;
             const int gj = (a.G == 1) ? 0 : c / a.TB;
             const double *cb = a.pos + (size_t)gj * 3 * P + (size_t)(c - gj * a.TB) * kTile + lane;
             const float xj = (float)(cb[0] - ccx), yj = (float)(cb[P] - ccy), zj = (float)(cb[2 * P] - ccz);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Bitwise comparison of two builds of libljmd.so on the same inputs (forces at n = 262144, a 25-step trajectory at
-n = 20000 with a partially filled last tile, the sharded form): each build runs in its own child process and writes
+n = 20000 with a partially filled last tile, the sharded form, the mixed-precision mode): each build runs in its own child process and writes
 its arrays; used to check that a refactoring of the pair kernel did not change a single bit.  usage:
 compare_builds.py <libA.so> <libB.so>"""
 import os
@@ -30,6 +30,14 @@ p, r, v = synthetic.make_config(65536, seed=5)
 with Engine(p, devices=[0, 0, 0, 0]) as e:
     e.set_state(r[0], r[1], r[2], v[0], v[1], v[2]); e.compute_forces()
     out["multi65536"] = np.stack(e.verlet_steps(12))
+p, r, v = synthetic.make_config(262144)
+with Engine(p, precision_mode=1) as e:            # mixed: fp32 far kernel + fp64 near kernel
+    e.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+    out["mixed_sc262144"] = np.array(e.compute_forces()); out["mixed_a262144"] = np.stack(e.get_state(("a",))["a"])
+p, r, v = synthetic.make_config(20000, seed=3)
+with Engine(p, precision_mode=1) as e:
+    e.set_state(r[0], r[1], r[2], v[0], v[1], v[2]); e.compute_forces()
+    out["mixed_traj20000"] = np.stack(e.verlet_steps(25))
 np.savez(sys.argv[1], **out)
 """ % str(ROOT)
 res = []
