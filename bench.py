@@ -238,12 +238,31 @@ def main() -> None:
         sim.collect(args.steps)
         liquid = (el_liq, prof_liq["pair_ms"], done)
 
+    # the production loop's rate: the reference reads epot / d_epot / dd_epot only every output_interval steps
+    # (md_simulation_program.f90:361; 100 in its input file), so the driver runs the steps in between with the
+    # forces-only pair kernel (ljmd_enqueue_steps_sampled).  The same K steps again as ONE sampled segment, in the
+    # state the previous leg left; the trajectory is bit-identical.  Reported beside the headline, never as `value`.
+    sampled = None
+    if not args.no_liquid and n >= 4096:
+        eng.profile_enable(True)
+        barrier()
+        t2 = time.perf_counter()
+        sim.enqueue_steps(args.steps, sampled=True)
+        barrier()
+        el_s = time.perf_counter() - t2
+        prof_s = eng.profile_read()
+        eng.profile_enable(False)
+        sc_s = sim.collect(args.steps)
+        sampled = (el_s, prof_s["pair_ms"], bool(np.isfinite(sc_s[0][-1])), int(np.count_nonzero(np.isnan(sc_s[0]))))
+
     if dist is not None:
-        t = torch.tensor([elapsed, liquid[0] if liquid else 0.0], dtype=torch.float64)
+        t = torch.tensor([elapsed, liquid[0] if liquid else 0.0, sampled[0] if sampled else 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
         if liquid:
             liquid = (float(t[1].item()),) + liquid[1:]
+        if sampled:
+            sampled = (float(t[2].item()),) + sampled[1:]
 
     if rank == 0:
         steps_per_s = args.steps / elapsed
@@ -284,6 +303,12 @@ def main() -> None:
                            "pair_kernel_ms_avg": liquid[1],
                            "note": "same K steps timed again in the equilibrated liquid; not the headline"}}
                if liquid else {}),
+            **({"steps_per_s_sampled_segment": args.steps / sampled[0],
+                "sampled_segment": {"ms_per_step": 1e3 * sampled[0] / args.steps, "pair_kernel_ms_avg": sampled[1],
+                                    "observables_on_last_step_finite": sampled[2], "steps_without_energy_sums": sampled[3],
+                                    "note": "same K steps as one ljmd_enqueue_steps_sampled segment (liquid state): energy sums "
+                                            "only on the step the reference samples (output_interval); not the headline"}}
+               if sampled else {}),
             "energy_check": {"etot_first": float(etot[0]), "etot_last": float(etot[-1]),
                              "rel_drift": float(abs(etot[-1] - etot[0]) / abs(etot[0]))},
         }
@@ -306,10 +331,17 @@ def main() -> None:
             hits = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{stem}"))
             return hits[-1] if hits else None
 
+        def headline_instances(kernels, name):
+            """template instances of the pair kernel in a committed PMC summary, without the forces-only ones
+            (<..., false>: they run only in the sampled-segment leg)"""
+            hits = {key: val for key, val in kernels.items() if key.startswith("ljmdk::" + name + "<")}
+            full = [val for key, val in hits.items() if not key.rstrip().endswith(("false>", "0>", "(bool)0>"))]
+            return full or list(hits.values())
+
         pmc = committed("final_pmc_hbm_traffic.json")
         if world == 1 and n == N_PARTICLES and args.mode == "fp64" and pmc:
             kernels = json.loads(pmc.read_text())["kernels"]
-            hits = [val for key, val in kernels.items() if key.startswith("ljmdk::" + kernel_name + "<")]
+            hits = headline_instances(kernels, kernel_name)
             k = max(hits, key=lambda val: val["hbm_bytes_per_launch"]) if hits else {}   # the template instance that ran
             if k:
                 line["roofline"]["traffic"] = k["hbm_bytes_per_launch"]
@@ -318,7 +350,7 @@ def main() -> None:
         valu = committed("final_pmc_valu.json")
         if world == 1 and n == N_PARTICLES and args.mode == "fp64" and valu:
             kernels = json.loads(valu.read_text())["kernels"]
-            hits = [val for key, val in kernels.items() if key.startswith("ljmdk::" + kernel_name + "<")]
+            hits = headline_instances(kernels, kernel_name)
             k = max(hits, key=lambda val: val.get("SQ_INSTS_VALU", 0.0)) if hits else {}
             if k.get("valu_issue_frac"):
                 line["roofline"].update({"valu_issue_frac": k["valu_issue_frac"],

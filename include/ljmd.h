@@ -134,7 +134,9 @@ int ljmd_compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot
  * Requires valid resident accelerations (ljmd_compute_forces or ljmd_set_accel
  * first, as the reference's drivers do at md_simulation_program.f90:236).
  * epot/ekin/d_epot/dd_epot: each NULL or an array of nsteps doubles receiving the
- * value after every step.
+ * value after every step.  With epot, d_epot and dd_epot all NULL nobody reads the
+ * potential-energy sums and the steps run the forces-only pair kernel (see
+ * ljmd_enqueue_steps_sampled); the trajectory is bit-for-bit the same.
  */
 int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps,
                       double *epot, double *ekin, double *d_epot, double *dd_epot);
@@ -158,6 +160,17 @@ int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps,
  */
 #define LJMD_MAX_PENDING_STEPS 4096
 int ljmd_enqueue_steps(ljmd_t *h, int32_t nsteps);
+/* As ljmd_enqueue_steps, for a segment of which only the LAST step is sampled -- the reference reads epot, d_epot,
+ * dd_epot only where mod(step, output_interval) == 0 (md_simulation_program.f90:361; output_interval = 100 in the
+ * reference's input file) although lj_potential_energy.f90 sums them on every call.  The pair kernel of the other
+ * nsteps - 1 steps leaves the two energy sums out (forces-only instantiation, -6 % kernel time at n = 262144);
+ * positions, velocities, accelerations and ekin are bit-for-bit those of ljmd_enqueue_steps, and ljmd_collect_steps
+ * returns NaN for epot, d_epot, dd_epot of the steps that were not sampled. */
+int ljmd_enqueue_steps_sampled(ljmd_t *h, int32_t nsteps);
+/* The same switch for the phase API of a sharded engine (ljmd_step_begin / ljmd_step_forces / ljmd_step_finish):
+ * on = 0 makes the following force evaluations forces-only until it is switched on again (default on).
+ * ljmd_compute_forces always evaluates the sums. */
+int ljmd_set_observables(ljmd_t *h, int32_t on);
 int ljmd_collect_steps(ljmd_t *h, int32_t nsteps,
                        double *epot, double *ekin, double *d_epot, double *dd_epot);
 int ljmd_snapshot_begin(ljmd_t *h);

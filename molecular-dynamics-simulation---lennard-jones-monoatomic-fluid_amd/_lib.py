@@ -57,6 +57,8 @@ PROTOTYPES = {
     "ljmd_compute_forces": (C.c_int, [C.c_void_p] + [c_double_p] * 3),
     "ljmd_verlet_steps": (C.c_int, [C.c_void_p, C.c_int32] + [c_double_p] * 4),
     "ljmd_enqueue_steps": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ljmd_enqueue_steps_sampled": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ljmd_set_observables": (C.c_int, [C.c_void_p, C.c_int32]),
     "ljmd_collect_steps": (C.c_int, [C.c_void_p, C.c_int32] + [c_double_p] * 4),
     "ljmd_snapshot_begin": (C.c_int, [C.c_void_p]),
     "ljmd_snapshot_end": (C.c_int, [C.c_void_p] + [c_double_p] * 12),

@@ -91,6 +91,7 @@ N3Args n3_args(ljmd_t *h)
     a.Q = h->Q;
     a.dchunk = h->dchunk;
     a.xcd_remap = 0;
+    a.energy = h->want_energy ? 1 : 0;
     a.RT = h->rt;
     a.L = h->L;
     a.invL = h->invL;
@@ -957,7 +958,10 @@ int ljmd_compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot
     LJMD_HIP(h, hipSetDevice(h->device));
     EventSet *q = next_events(h);
     if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
+    const bool keep = h->want_energy;
+    h->want_energy = true;                      // this call exists to return the three sums
     int rc_ = enqueue_forces(h, false, q);
+    h->want_energy = keep;
     if (rc_ != LJMD_OK) return rc_;
     rc_ = fetch_ring(h, 1);
     if (rc_ != LJMD_OK) return rc_;
@@ -975,18 +979,21 @@ int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, dou
         return fail(h, LJMD_ERR_STATE,
                     "ljmd_verlet_steps: accelerations not initialised (call ljmd_compute_forces first)");
     if (h->poisoned) return fail(h, LJMD_ERR_STATE, "ljmd_verlet_steps: handle poisoned by an earlier failure; call ljmd_set_state");
+    // nobody reads the potential-energy sums (the warm-up of the initial-configuration driver): forces-only pair kernel
+    const bool keep = h->want_energy, wanted = keep && (epot || d_epot || dd_epot);
     if (h->multi) {
-        int done_m = 0;
-        while (done_m < nsteps) {
+        int done_m = 0, rc_ = LJMD_OK;
+        ljmdm::set_observables(h, wanted);
+        while (done_m < nsteps && rc_ == LJMD_OK) {
             const int batch = std::min<int>(nsteps - done_m, (int)kRingCap);
-            int rc_ = ljmdm::enqueue_steps(h, batch);
+            rc_ = ljmdm::enqueue_steps(h, batch, false);
             if (rc_ == LJMD_OK)
                 rc_ = ljmdm::collect_steps(h, batch, epot ? epot + done_m : nullptr, ekin ? ekin + done_m : nullptr,
                                            d_epot ? d_epot + done_m : nullptr, dd_epot ? dd_epot + done_m : nullptr);
-            if (rc_ != LJMD_OK) return rc_;
             done_m += batch;
         }
-        return LJMD_OK;
+        ljmdm::set_observables(h, keep);
+        return rc_;
     }
     if (h->G != 1)
         return fail(h, LJMD_ERR_STATE, "ljmd_verlet_steps: sharded engine; use ljmd_step_begin/finish");
@@ -994,15 +1001,18 @@ int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, dou
     int done = 0;
     while (done < nsteps) {
         const int batch = std::min<int>(nsteps - done, (int)kRingCap);
+        h->want_energy = wanted;
         for (int s = 0; s < batch; ++s) {
             EventSet *q = next_events(h);
             int rc_ = enqueue_drift(h, q);
             if (rc_ == LJMD_OK) rc_ = enqueue_forces(h, true, q);
             if (rc_ != LJMD_OK) {
+                h->want_energy = keep;
                 h->poisoned = true;      // a step is half enqueued: no rollback, the state is no longer a trajectory point
                 return rc_;
             }
         }
+        h->want_energy = keep;
         int rc_ = fetch_ring(h, (unsigned)batch);
         if (rc_ != LJMD_OK) return rc_;
         for (int s = 0; s < batch; ++s)
@@ -1016,7 +1026,32 @@ int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, dou
 
 // ---- asynchronous production loop ---------------------------------------------
 
+namespace {
+int enqueue_steps_impl(ljmd_t *h, int32_t nsteps, bool sampled);
+}
+
 int ljmd_enqueue_steps(ljmd_t *h, int32_t nsteps)
+{
+    return enqueue_steps_impl(h, nsteps, false);
+}
+
+int ljmd_enqueue_steps_sampled(ljmd_t *h, int32_t nsteps)
+{
+    return enqueue_steps_impl(h, nsteps, true);
+}
+
+int ljmd_set_observables(ljmd_t *h, int32_t on)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_set_observables: NULL handle");
+    if (h->multi) return ljmdm::set_observables(h, on != 0);
+    h->want_energy = on != 0;
+    return LJMD_OK;
+}
+
+namespace {
+// sampled: only the LAST of the nsteps evaluates the potential-energy sums (the step the reference samples,
+// md_simulation_program.f90:361); positions, velocities, accelerations and ekin do not depend on them
+int enqueue_steps_impl(ljmd_t *h, int32_t nsteps, bool sampled)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_enqueue_steps: NULL handle");
     if (nsteps < 0) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_enqueue_steps: nsteps < 0");
@@ -1025,7 +1060,7 @@ int ljmd_enqueue_steps(ljmd_t *h, int32_t nsteps)
         return fail(h, LJMD_ERR_STATE,
                     "ljmd_enqueue_steps: accelerations not initialised (call ljmd_compute_forces first)");
     if (h->poisoned) return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: handle poisoned by an earlier failure; call ljmd_set_state");
-    if (h->multi) return ljmdm::enqueue_steps(h, nsteps);
+    if (h->multi) return ljmdm::enqueue_steps(h, nsteps, sampled);
     if (h->G != 1)
         return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: sharded engine; use ljmd_step_begin/finish");
     static_assert(LJMD_MAX_PENDING_STEPS == kRingCap, "LJMD_MAX_PENDING_STEPS out of sync with the record ring");
@@ -1033,17 +1068,22 @@ int ljmd_enqueue_steps(ljmd_t *h, int32_t nsteps)
         return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: %u + %d pending steps exceed LJMD_MAX_PENDING_STEPS",
                     h->ring_issued - h->ring_consumed, nsteps);
     LJMD_HIP(h, hipSetDevice(h->device));
+    const bool keep = h->want_energy;
     for (int s = 0; s < nsteps; ++s) {
         EventSet *q = next_events(h);
+        if (sampled) h->want_energy = s == nsteps - 1;
         int rc_ = enqueue_drift(h, q);
         if (rc_ == LJMD_OK) rc_ = enqueue_forces(h, true, q);
         if (rc_ != LJMD_OK) {
+            h->want_energy = keep;
             h->poisoned = true;
             return rc_;
         }
     }
+    h->want_energy = keep;
     return LJMD_OK;
 }
+}  // namespace
 
 int ljmd_collect_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, double *d_epot, double *dd_epot)
 {

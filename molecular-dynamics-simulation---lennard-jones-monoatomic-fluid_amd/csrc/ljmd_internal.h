@@ -63,6 +63,7 @@ struct N3Args {
     int NG, NGo, Dmax, Q;   // row groups in total / owned by this rank (NGo = TB / RT, NG = G * NGo), Q = (Dmax+1)*RT
     int RT;                 // tiles per row group: 4 for large systems, 1 or 2 to give small ones enough work items
     int dchunk;             // offsets d per grid.y slice
+    int energy;             // 0: forces only -- the energy sums are not accumulated and the workgroup partials are NaN
     int xcd_remap;          // C > 0: XCD-aware mapping, chunks of C consecutive row groups per XCD (gridDim.x % (8 C) == 0)
     double L, invL, rc2;
 };

@@ -287,7 +287,8 @@ __device__ __forceinline__ double dpp_rotate(double v)
     return __hiloint2double(hi, lo);
 }
 
-template <bool LANE_PRED, int NU, bool INNER = false>
+// ENERGY = false: the two energy sums are not accumulated (steps whose observables nobody reads, see N3Args::energy)
+template <bool LANE_PRED, int NU, bool INNER = false, bool ENERGY = true>
 __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
                                         double xj, double yj, double zj,
                                         double L, double invL, double rc2, bool lane_ok,
@@ -317,8 +318,10 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
         const double u = rcp_newton(r2);
         const double u3 = u * u * u;
         const double u6 = u3 * u3;
-        s12 += u6;
-        s6 += u3;
+        if constexpr (ENERGY) {
+            s12 += u6;
+            s6 += u3;
+        }
         const double g = fma(2.0, u6, -u3) * u;
         ax = fma(g, dx, ax);
         ay = fma(g, dy, ay);
@@ -346,7 +349,7 @@ __device__ __forceinline__ void pair_geom(double xi, double yi, double zi, doubl
 }
 
 // ... and everything behind the reciprocal u = 1 / r^2
-template <bool INNER>
+template <bool INNER, bool ENERGY>
 __device__ __forceinline__ void pair_apply(double u, double dx, double dy, double dz, double r2, double rc2, double &ax,
                                            double &ay, double &az, double &jx, double &jy, double &jz, double &s12,
                                            double &s6)
@@ -356,8 +359,10 @@ __device__ __forceinline__ void pair_apply(double u, double dx, double dy, doubl
     if (in) {
         const double u3 = u * u * u;
         const double u6 = u3 * u3;
-        s12 += u6;
-        s6 += u3;
+        if constexpr (ENERGY) {
+            s12 += u6;
+            s6 += u3;
+        }
         const double g = fma(2.0, u6, -u3) * u;
         ax = fma(g, dx, ax);
         ay = fma(g, dy, ay);
@@ -393,7 +398,7 @@ constexpr int kLdsAxis = 2 * kTile;         // doubles per axis in the parked co
 // pair is finite and far from under/overflow (r^2 <= 3 (L/2 + tile)^2, product of four <= 1e17 at L = 69), lanes
 // outside the cutoff compute a reciprocal they do not use.  Each 1/r^2 carries three roundings instead of one
 // (<= 1.5 ulp); the parity tests hold their bounds unchanged.
-template <int RT, int NU, bool MASKED, bool INNER, bool BATCH = false>
+template <int RT, int NU, bool MASKED, bool INNER, bool BATCH = false, bool ENERGY = true>
 __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const double (&yi)[RT],
                                                  const double (&zi)[RT], double (&ax)[RT],
                                                  double (&ay)[RT], double (&az)[RT],
@@ -427,12 +432,12 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const d
             }
 #pragma unroll
             for (int k = 0; k < RT; ++k)
-                pair_apply<INNER>(u[k], dx[k], dy[k], dz[k], r2[k], rc2, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+                pair_apply<INNER, ENERGY>(u[k], dx[k], dy[k], dz[k], r2[k], rc2, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
         } else {
 #pragma unroll
             for (int k = 0; k < RT; ++k)
                 if (!MASKED || ((mb >> k) & 1u))
-                    pair_n3<false, NU, INNER>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
+                    pair_n3<false, NU, INNER, ENERGY>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
                                               ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
         }
         jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
@@ -443,7 +448,7 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const d
 #pragma unroll
         for (int k = 0; k < RT; ++k)
             if (!MASKED || ((mb >> k) & 1u))
-                pair_n3<false, NU, INNER>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
+                pair_n3<false, NU, INNER, ENERGY>(xi[k], yi[k], zi[k], xj, yj, zj, L, invL, rc2, true, sx, sy, sz,
                                           ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
         xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
         jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
@@ -488,7 +493,7 @@ __device__ __forceinline__ void wave_lds_sync()
 // otherwise they are loaded here and parked.  after_classification() is called just before the rotation loop (which
 // touches LDS only): the place to issue the NEXT tile's LDS-DMA so that it overlaps the whole loop and no later
 // s_waitcnt vmcnt of this tile has to wait for it.
-template <int RT, int W, bool PREFETCHED, typename AFTER>
+template <int RT, int W, bool PREFETCHED, bool ENERGY, typename AFTER>
 __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, int d, int l, unsigned mb, unsigned desc,
                                              const double (&xi)[RT],
                                              const double (&yi)[RT], const double (&zi)[RT], double (&ax)[RT],
@@ -523,11 +528,11 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
                 if (!((mb >> k) & 1u)) continue;
                 if (k == l) {
                     if (s >= 1 && s <= 32)
-                        pair_n3<true, 7>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2,
+                        pair_n3<true, 7, false, ENERGY>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2,
                                          s < 32 || lane < 32, 0.0, 0.0, 0.0, ax[k], ay[k], az[k], jx,
                                          jy, jz, s12, s6);
                 } else {
-                    pair_n3<false, 7>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0,
+                    pair_n3<false, 7, false, ENERGY>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0,
                                       0.0, 0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
                 }
             }
@@ -549,10 +554,10 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
     }
 #endif
 #define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
-    column_tile_loop<RT, NU_, MASKED_, INNER_, false>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
+    column_tile_loop<RT, NU_, MASKED_, INNER_, false, ENERGY>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
                                                   a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
 #define LJMD_LOOP_ALL(NU_, INNER_)                                                                           \
-    column_tile_loop<RT, NU_, false, INNER_, (RT == 2 || RT == 4) && LJMD_BATCH_RCP>(                              \
+    column_tile_loop<RT, NU_, false, INNER_, (RT == 2 || RT == 4) && LJMD_BATCH_RCP, ENERGY>(                              \
         xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL, a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
     // all row tiles active AND no padding slot anywhere in the tile pair: the unmasked loop with the batched
     // reciprocal; otherwise the masked loop (correct for any mb; a NaN padding slot must not enter a product)
@@ -606,7 +611,7 @@ __device__ __forceinline__ void tile_to_lds_async(const N3Args &a, int lane, int
 #define LJMD_PREFETCH 0
 #endif
 
-template <int MIN_WAVES, int RT, int W>
+template <int MIN_WAVES, int RT, int W, bool ENERGY>
 __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
 {
     constexpr bool kPrefetch = (W == 1) && LJMD_PREFETCH && LJMD_LDS_POS;
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             double jx = 0.0, jy = 0.0, jz = 0.0;
             double *pk_cur = cur ? parked_all[0][1] : parked_all[0][0];
             double *pk_next = cur ? parked_all[0][0] : parked_all[0][1];
-            n3_tile_pass<RT, W, true>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, pk_cur,
+            n3_tile_pass<RT, W, true, ENERGY>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, pk_cur,
                                       [&]() { if (tn < nt) tile_to_lds_async(a, lane, cn, pk_next); },
                                       jx, jy, jz, s12, s6);
             double *o = a.slab_j + blk * (3 * kTile) + lane;
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             const bool have = mb != 0;
             double jx = 0.0, jy = 0.0, jz = 0.0;
             if (have)
-                n3_tile_pass<RT, W, false>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, parked,
+                n3_tile_pass<RT, W, false, ENERGY>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, parked,
                                            []() {}, jx, jy, jz, s12, s6);
             if constexpr (W == 1) {
                 if (have) {
@@ -776,7 +781,8 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             si[2 * P + slot] = az[k];
         }
     }
-    const double t12 = wave_sum(s12), t6 = wave_sum(s6);
+    // without the sums the step's potential-energy observables come out as NaN, never as a stale or partial number
+    const double t12 = ENERGY ? wave_sum(s12) : __builtin_nan(""), t6 = ENERGY ? wave_sum(s6) : __builtin_nan("");
     if (lane == 0) {
         double *w = a.wg_part + 2 * (((size_t)by * gridDim.x + bx) * W + wv);
         w[0] = t12;
@@ -803,7 +809,7 @@ __device__ __forceinline__ float dpp_rotate_f32(float v)
 
 // GEN: bit k set = axis k needs the general minimum image; clear = its common image shift is already folded
 // into the row offsets (0 = the former UNIFORM, 7 = all general)
-template <int GEN>
+template <int GEN, bool ENERGY>
 __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float xj, float yj, float zj,
                                             float Lf, float invLf, float rc2f,
                                             float &ax, float &ay, float &az, float &jx, float &jy, float &jz,
@@ -818,8 +824,10 @@ __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float 
         const float u = __builtin_amdgcn_rcpf(r2);
         const float u3 = u * u * u;
         const float u6 = u3 * u3;
-        s12 += u6;
-        s6 += u3;
+        if constexpr (ENERGY) {
+            s12 += u6;
+            s6 += u3;
+        }
         const float g = fmaf(2.0f, u6, -u3) * u;
         ax = fmaf(g, dx, ax);
         ay = fmaf(g, dy, ay);
@@ -830,7 +838,7 @@ __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float 
     }
 }
 
-template <int GEN, bool MASKED>
+template <int GEN, bool MASKED, bool ENERGY>
 __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], const float (&py)[kRowTiles],
                                                 const float (&pz)[kRowTiles], float (&fx)[kRowTiles],
                                                 float (&fy)[kRowTiles], float (&fz)[kRowTiles],
@@ -842,13 +850,14 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k)
             if (!MASKED || ((mb >> k) & 1u))
-                pair_n3_f32<GEN>(px[k], py[k], pz[k], xj, yj, zj, Lf, invLf, rc2f, fx[k], fy[k], fz[k],
+                pair_n3_f32<GEN, ENERGY>(px[k], py[k], pz[k], xj, yj, zj, Lf, invLf, rc2f, fx[k], fy[k], fz[k],
                                      jx, jy, jz, s12, s6);
         xj = dpp_rotate_f32(xj); yj = dpp_rotate_f32(yj); zj = dpp_rotate_f32(zj);
         jx = dpp_rotate_f32(jx); jy = dpp_rotate_f32(jy); jz = dpp_rotate_f32(jz);
     }
 }
 
+template <bool ENERGY>
 __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
 {
     const int lane = threadIdx.x;                              // one wave per workgroup (see pair_n3_kernel)
@@ -927,7 +936,7 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
             }
             float jx = 0.0f, jy = 0.0f, jz = 0.0f, t12 = 0.0f, t6 = 0.0f;
 #define LJMD_LOOP32(GEN_, MASKED_)                                                                              \
-    column_loop_f32<GEN_, MASKED_>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6)
+    column_loop_f32<GEN_, MASKED_, ENERGY>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6)
             const bool all4 = mb == kAllRows;
             if (gen == 0)      { if (all4) LJMD_LOOP32(0, false); else LJMD_LOOP32(0, true); }
             else if (gen == 1) { if (all4) LJMD_LOOP32(1, false); else LJMD_LOOP32(1, true); }
@@ -961,7 +970,7 @@ __global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
             si[2 * P + slot] = az[k];
         }
     }
-    const double r12 = wave_sum(s12), r6 = wave_sum(s6);
+    const double r12 = ENERGY ? wave_sum(s12) : __builtin_nan(""), r6 = ENERGY ? wave_sum(s6) : __builtin_nan("");
     if (lane == 0) {
         double *w = a.wg_part + 2 * ((size_t)by * gridDim.x + bx);
         w[0] = r12;
@@ -1454,22 +1463,32 @@ hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t 
 {
     // 3 waves per SIMD (168 VGPRs, no spills) is the measured optimum of the register budget; wg_waves = waves
     // (= consecutive row groups) per workgroup, 2 and 4 only for 4-tile row groups
-    if (a.RT == 1)
-        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1>), grid, dim3(kTile), 0, s, a);
+    // a.energy == 0 (forces only) exists for the one-wave workgroups; the LDS-combining forms always keep the sums
+    if (a.RT == 1 && !a.energy)
+        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, false>), grid, dim3(kTile), 0, s, a);
+    else if (a.RT == 1)
+        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, true>), grid, dim3(kTile), 0, s, a);
+    else if (a.RT == 2 && !a.energy)
+        hipLaunchKernelGGL((pair_n3_kernel<3, 2, 1, false>), grid, dim3(kTile), 0, s, a);
     else if (a.RT == 2)
-        hipLaunchKernelGGL((pair_n3_kernel<3, 2, 1>), grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, 2, 1, true>), grid, dim3(kTile), 0, s, a);
     else if (wg_waves == 4)
-        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 4>), grid, dim3(4 * kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 4, true>), grid, dim3(4 * kTile), 0, s, a);
     else if (wg_waves == 2)
-        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 2>), grid, dim3(2 * kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 2, true>), grid, dim3(2 * kTile), 0, s, a);
+    else if (!a.energy)
+        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 1, false>), grid, dim3(kTile), 0, s, a);
     else
-        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 1>), grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, kRowTiles, 1, true>), grid, dim3(kTile), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(pair_n3_f32_kernel, grid, dim3(kTile), 0, s, a);
+    if (a.energy)
+        hipLaunchKernelGGL(pair_n3_f32_kernel<true>, grid, dim3(kTile), 0, s, a);
+    else
+        hipLaunchKernelGGL(pair_n3_f32_kernel<false>, grid, dim3(kTile), 0, s, a);
     return hipGetLastError();
 }
 

@@ -319,27 +319,43 @@ int get_state(ljmd_t *h, double *const p[12])
     return LJMD_OK;
 }
 
+int set_observables(ljmd_t *h, bool on)
+{
+    ljmd_multi *m = h->multi;
+    h->want_energy = on;
+    for (int g = 0; g < m->G; ++g) m->eng[g]->want_energy = on;
+    return LJMD_OK;
+}
+
 int compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot)
 {
     ljmd_multi *m = h->multi;
     const std::vector<EventSet *> q(m->G, nullptr);
-    LJMD_TRY(enqueue_forces_all(h, false, q));
+    const bool keep = h->want_energy;
+    set_observables(h, true);                   // this call exists to return the three sums
+    const int rc_ = enqueue_forces_all(h, false, q);
+    set_observables(h, keep);
+    if (rc_ != LJMD_OK) return rc_;
     h->have_accel = true;
     return collect(h, 1, epot, nullptr, d_epot, dd_epot);
 }
 
-int enqueue_steps(ljmd_t *h, int32_t nsteps)
+int enqueue_steps(ljmd_t *h, int32_t nsteps, bool sampled)
 {
     if (pending(h) + (unsigned)nsteps > kRingCap)
         return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: %u + %d pending steps exceed LJMD_MAX_PENDING_STEPS", pending(h),
                     nsteps);
+    const bool keep = h->want_energy;
     for (int s = 0; s < nsteps; ++s) {
+        if (sampled) set_observables(h, s == nsteps - 1);
         const int rc_ = enqueue_one_step(h);
         if (rc_ != LJMD_OK) {
+            set_observables(h, keep);
             h->poisoned = true;        // some ranks are a phase ahead of the others
             return rc_;
         }
     }
+    set_observables(h, keep);
     return LJMD_OK;
 }
 

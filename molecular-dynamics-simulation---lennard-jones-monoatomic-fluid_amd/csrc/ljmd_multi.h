@@ -16,7 +16,8 @@ int set_accel(ljmd_t *h, const double *ax, const double *ay, const double *az);
 int set_unwrapped(ljmd_t *h, const double *ux, const double *uy, const double *uz);
 int get_state(ljmd_t *h, double *const p[12]);
 int compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot);
-int enqueue_steps(ljmd_t *h, int32_t nsteps);
+int enqueue_steps(ljmd_t *h, int32_t nsteps, bool sampled);
+int set_observables(ljmd_t *h, bool on);
 int collect_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, double *d_epot, double *dd_epot);
 int snapshot_begin(ljmd_t *h);
 int snapshot_end(ljmd_t *h, double *const p[12]);

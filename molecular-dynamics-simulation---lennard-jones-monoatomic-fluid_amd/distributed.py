@@ -144,12 +144,17 @@ class ShardedSimulation:
         e, _k, d, dd = self._combine(parts)
         return e[0], d[0], dd[0]
 
-    def enqueue_steps(self, nsteps: int) -> None:
-        """nsteps x {drift+kick1 | all-gather | forces+kick2}; no host synchronisation."""
-        for _ in range(nsteps):
+    def enqueue_steps(self, nsteps: int, sampled: bool = False) -> None:
+        """nsteps x {drift+kick1 | all-gather | forces+kick2}; no host synchronisation.
+        sampled: potential-energy sums on the last step only (ljmd_enqueue_steps_sampled / ljmd_set_observables)."""
+        for s in range(nsteps):
+            if sampled:
+                self.engine.set_observables(s == nsteps - 1)
             self.engine.step_begin()
             self.exchange_positions()
             self._finish(True)
+        if sampled:
+            self.engine.set_observables(True)
 
     def collect(self, nsteps: int):
         """-> (epot, ekin, d_epot, dd_epot) arrays of the last nsteps enqueued steps."""

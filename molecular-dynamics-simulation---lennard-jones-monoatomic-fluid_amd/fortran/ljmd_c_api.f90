@@ -18,7 +18,7 @@ module ljmd_c_api
   public :: ljmd_create, ljmd_create_multi, ljmd_destroy, ljmd_set_state, ljmd_set_accel, ljmd_set_unwrapped
   public :: ljmd_get_state, ljmd_compute_forces, ljmd_verlet_steps, ljmd_kinetic_energy
   public :: ljmd_last_error, ljmd_device_count, ljmd_profile_enable, ljmd_profile_read
-  public :: ljmd_enqueue_steps, ljmd_collect_steps, ljmd_snapshot_begin, ljmd_snapshot_end
+  public :: ljmd_enqueue_steps, ljmd_enqueue_steps_sampled, ljmd_collect_steps, ljmd_snapshot_begin, ljmd_snapshot_end
   public :: ljmd_check, ljmd_error_text
 
   integer(c_int), parameter, public :: LJMD_OK = 0
@@ -117,6 +117,14 @@ module ljmd_c_api
 
     ! asynchronous production loop: enqueue returns at once, collect waits for the engine's stream
     function ljmd_enqueue_steps(handle, nsteps) bind(C, name="ljmd_enqueue_steps") result(status)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: nsteps
+      integer(c_int) :: status
+    end function
+
+    ! the same, the potential-energy sums evaluated on the LAST step only (the one the caller samples)
+    function ljmd_enqueue_steps_sampled(handle, nsteps) bind(C, name="ljmd_enqueue_steps_sampled") result(status)
       import :: c_int, c_int32_t, c_ptr
       type(c_ptr), value :: handle
       integer(c_int32_t), value :: nsteps

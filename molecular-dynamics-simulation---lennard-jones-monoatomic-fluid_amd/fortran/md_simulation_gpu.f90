@@ -35,7 +35,7 @@ program md_simulation_gpu
   real(kind=dp_kind) :: rc_over_L, target_total_energy
   real(kind=dp_kind) :: epot, ekin, etot, d_epot, dd_epot, time, temp_inst, press_inst, npd
   integer(kind=int_kind) :: step, count, k, num_samples
-  logical :: sample_now, async_io
+  logical :: sample_now, async_io, sampled_steps
   integer :: iu_rva, iu_out, ios, device, n_gpus
   integer(c_int32_t), allocatable, target :: device_list(:)
   character(len=256) :: env_list
@@ -56,6 +56,9 @@ program md_simulation_gpu
   async_io = .true.
   call get_environment_variable('LJMD_ASYNC_IO', env, status=ios)
   if (ios == 0 .and. len_trim(env) > 0) async_io = trim(env) /= '0'
+  sampled_steps = .true.
+  call get_environment_variable('LJMD_SAMPLED_STEPS', env, status=ios)
+  if (ios == 0 .and. len_trim(env) > 0) sampled_steps = trim(env) /= '0'
 
   n_gpus = 1
   call get_environment_variable('LJMD_GPUS', env, status=ios)
@@ -105,7 +108,7 @@ program md_simulation_gpu
   ! already running the steps up to the next sampling instant.  LJMD_ASYNC_IO=0 serialises the two
   ! (the next segment is enqueued only after the files are written) for A/B timing.
   count = segment_length(step)
-  call ljmd_check(ljmd_enqueue_steps(engine, count), engine, 'ljmd_enqueue_steps')
+  call enqueue_segment(count)
   do while (step < total_steps)
     call ljmd_check(ljmd_collect_steps(engine, count, c_loc(s_epot), c_loc(s_ekin), c_loc(s_depot), &
                                        c_loc(s_ddepot)), engine, 'ljmd_collect_steps')
@@ -118,7 +121,7 @@ program md_simulation_gpu
     sample_now = step > warmup_steps .and. mod(step, output_interval) == 0       ! :361
     if (sample_now) call ljmd_check(ljmd_snapshot_begin(engine), engine, 'ljmd_snapshot_begin')
     count = segment_length(step)
-    if (async_io .and. count > 0) call ljmd_check(ljmd_enqueue_steps(engine, count), engine, 'ljmd_enqueue_steps')
+    if (async_io .and. count > 0) call enqueue_segment(count)
     if (sample_now) then
       num_samples = num_samples + 1
       call stats_push(stats, epot, ekin, d_epot, dd_epot, temp_inst, press_inst)   ! T, P as md_means.f90:221,227
@@ -132,7 +135,7 @@ program md_simulation_gpu
       write(iu_rva) state%vx, state%vy, state%vz
       write(iu_rva) state%ax, state%ay, state%az
     end if
-    if (.not. async_io .and. count > 0) call ljmd_check(ljmd_enqueue_steps(engine, count), engine, 'ljmd_enqueue_steps')
+    if (.not. async_io .and. count > 0) call enqueue_segment(count)
   end do
   call system_clock(c1)
   close(iu_out)
@@ -146,6 +149,18 @@ program md_simulation_gpu
     0.5d0 * npd * (npd - 1.d0) * dble(total_steps) * dble(crate) / dble(max(c1 - c0, 1_8)), ' pair-interactions/s'
 
 contains
+
+  ! Only the last step of a segment is read below (epot = s_epot(count) ...): the reference samples at :361 and
+  ! nowhere else, so the steps in between run the forces-only pair kernel.  LJMD_SAMPLED_STEPS=0 evaluates the
+  ! energy sums on every step as lj_potential_energy.f90 does (A/B timing; r, v, a are bit-identical either way).
+  subroutine enqueue_segment(n_steps)
+    integer(kind=int_kind), intent(in) :: n_steps
+    if (sampled_steps) then
+      call ljmd_check(ljmd_enqueue_steps_sampled(engine, n_steps), engine, 'ljmd_enqueue_steps_sampled')
+    else
+      call ljmd_check(ljmd_enqueue_steps(engine, n_steps), engine, 'ljmd_enqueue_steps')
+    end if
+  end subroutine
 
   ! steps from `from_step` to the next sampling instant of :361 (or to the end of the run), capped by
   ! the engine's pending-step limit; 0 when the run is complete

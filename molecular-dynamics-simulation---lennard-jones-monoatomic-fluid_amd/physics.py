@@ -178,9 +178,21 @@ class Engine:
         self._ck(self._lib.ljmd_verlet_steps(self._h, nsteps, *[_ptr(o) for o in outs]))
         return tuple(outs)
 
+    def advance(self, nsteps: int) -> None:
+        """nsteps Verlet steps whose observables nobody reads (ljmd_verlet_steps with NULL outputs, as the warm-up of
+        the initial-configuration driver): forces-only pair kernel, same trajectory bit for bit"""
+        self._ck(self._lib.ljmd_verlet_steps(self._h, nsteps, None, None, None, None))
+
     # -- asynchronous production loop (snapshot I/O overlapped with the next steps) --------
-    def enqueue_steps(self, nsteps: int) -> None:
-        self._ck(self._lib.ljmd_enqueue_steps(self._h, nsteps))
+    def enqueue_steps(self, nsteps: int, sampled: bool = False) -> None:
+        """sampled: only the last of the nsteps evaluates epot, d_epot, dd_epot (the step the reference samples,
+        md_simulation_program.f90:361); collect_steps returns NaN for the others.  r, v, a, ekin are unchanged."""
+        fn = self._lib.ljmd_enqueue_steps_sampled if sampled else self._lib.ljmd_enqueue_steps
+        self._ck(fn(self._h, nsteps))
+
+    def set_observables(self, on: bool) -> None:
+        """phase API (sharded engines): forces-only force evaluations while off"""
+        self._ck(self._lib.ljmd_set_observables(self._h, 1 if on else 0))
 
     def collect_steps(self, nsteps: int):
         outs = [np.empty(nsteps, dtype=np.float64) for _ in range(4)]

@@ -10,6 +10,8 @@ Tolerances:
 The GPU sums pairs in a different order than the sequential i<j loop, so bitwise identity
 with the reference is not attainable and not claimed.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -640,6 +642,48 @@ def test_async_steps_and_snapshot_equal_the_synchronous_path(golden):
     for key in ("r", "ru", "v", "a"):
         assert np.array_equal(np.stack(snap[key]), np.stack(st_a[key])), key
         assert np.array_equal(np.stack(fin[key]), np.stack(st_b[key])), key
+
+
+@pytest.mark.parametrize("n,mode,devices,steps", [
+    (4096, 0, None, 40), (20000, 0, None, 25), (65536, 0, None, 12), (262144, 0, None, 6), (262144, 1, None, 6),
+    (65536, 0, [0, 0, 0, 0], 12)])
+def test_sampled_segments_skip_the_energy_sums_and_nothing_else(n, mode, devices, steps):
+    """ljmd_enqueue_steps_sampled (potential-energy sums on the last step of the segment only -- where the reference
+    samples, md_simulation_program.f90:361) and ljmd_verlet_steps with NULL outputs against the every-step path:
+    r, ru, v, a, ekin of every step and the sampled step's epot / d_epot / dd_epot are BITWISE equal; the steps in
+    between report NaN (never a stale number) wherever the forces-only kernel exists (Newton-3 kernels, one wave per
+    workgroup)."""
+    p, r, v = synthetic.make_config(n, seed=11)
+    kw = dict(precision_mode=mode) if devices is None else dict(precision_mode=mode, devices=devices)
+    with Engine(p, **kw) as ref:
+        ref.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        ref.compute_forces()
+        want = np.stack(ref.verlet_steps(steps))                 # rows epot, ekin, d_epot, dd_epot
+        want2 = np.stack(ref.verlet_steps(steps))
+        st = ref.get_state()
+        kernel = ref.pair_kernel_name()
+    with Engine(p, **kw) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        eng.compute_forces()
+        eng.enqueue_steps(steps, sampled=True)
+        got = np.stack(eng.collect_steps(steps))
+        eng.advance(steps - 1)                                   # nobody reads these steps' sums
+        got2 = np.stack(eng.verlet_steps(1))
+        fin = eng.get_state()
+        sc = eng.compute_forces()                                # always evaluates the sums
+    with Engine(p, **kw) as chk:
+        chk.set_state(*fin["r"], *fin["v"])
+        # (a fresh engine sorts the particles into another slot order: same sums, other rounding)
+        assert np.allclose(np.array(chk.compute_forces()), np.array(sc), rtol=1e-12, atol=0.0)
+    assert np.array_equal(got[1], want[1])                       # ekin, every step
+    assert np.array_equal(got[:, -1], want[:, -1])               # the sampled step, all four
+    assert np.array_equal(got2[:, 0], want2[:, -1])
+    between = got[[0, 2, 3], :-1]
+    assert np.all(np.isnan(between) | (between == want[[0, 2, 3], :-1]))
+    if "n3" in kernel and os.environ.get("LJMD_N3_WG_WAVES", "1") == "1":
+        assert np.all(np.isnan(between)), kernel
+    for key in ("r", "ru", "v", "a"):
+        assert np.array_equal(np.stack(fin[key]), np.stack(st[key])), key
 
 
 def test_async_api_sequence_errors():

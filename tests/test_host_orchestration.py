@@ -41,6 +41,8 @@ def drive(eng, r, v, steps):
     st = eng.get_state()
     eng.set_accel(*st["a"]); eng.set_unwrapped(*st["ru"])
     eng.verlet_steps(3)
+    eng.enqueue_steps(6, sampled=True); eng.collect_steps(6)      # forces-only steps, sums on the last one
+    eng.advance(4)
     return st
 
 # single engines: gather kernel sizes, Newton-3 with 1 / 2 / 4 tiles per row group, padded shards, mixed precision
