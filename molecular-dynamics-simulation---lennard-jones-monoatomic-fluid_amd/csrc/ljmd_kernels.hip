@@ -385,6 +385,9 @@ __device__ __forceinline__ void pair_apply(double u, double dx, double dy, doubl
 #ifndef LJMD_N3_UNROLL
 #define LJMD_N3_UNROLL 8
 #endif
+#ifndef LJMD_FOLD_IMAGES
+#define LJMD_FOLD_IMAGES 1     // a tile pair's common periodic image is added to the column tile once (n3_tile_pass)
+#endif
 #ifndef LJMD_BATCH_RCP
 #define LJMD_BATCH_RCP 1       // one reciprocal per step for all row tiles of a lane (column_tile_loop<..., BATCH>)
 #endif
@@ -541,6 +544,23 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
         }
         return;
     }
+#if LJMD_FOLD_IMAGES
+    // A common image of the whole tile pair is subtracted from the column tile ONCE, here, instead of from every
+    // pair's difference: d = xi - (xj + nL).  Three additions per pass replace one subtraction per pair and imaged
+    // axis, and the loop variants with a common image collapse into the ones without (nu 16, 17, 18, 0 -> 8;
+    // 1, 2, 4 -> 24, 25, 26).  xj + nL is rounded at a magnitude <= 2 L where the reference rounds xi - xj at
+    // <= L before its exact minimum-image correction (geometry_pbc.f90:86): the same order of error (<= 2 ulp(L)),
+    // not the same bits.
+    static_assert(!PREFETCHED, "LDS-DMA parks the tile without passing through registers: build with -DLJMD_FOLD_IMAGES=0");
+    const bool general_all = nu == 7;
+    int loop = nu;
+    if (!general_all) {
+        xj += sx; yj += sy; zj += sz;                   // 0.0 on a general axis and where the image is n = 0
+        loop = (nu == 1) ? 24 : (nu == 2) ? 25 : (nu == 4) ? 26 : (nu >= 24) ? nu : 8;
+    }
+#else
+    const int loop = nu;
+#endif
 #if LJMD_LDS_POS
     if constexpr (!PREFETCHED) {
         wave_lds_sync<W>();                            // the previous tile's reads are done
@@ -569,23 +589,25 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
         atomicAdd(&g_variant_stats[56 + __builtin_popcount(mb)], 1ull);      // column-tile passes by active row tiles
     }
 #endif
-    if (nu == 8 && inner) { if (all4) LJMD_LOOP_ALL(8, true); else LJMD_LOOP(8, true, true); }
-    else if (nu == 8)     { if (all4) LJMD_LOOP_ALL(8, false); else LJMD_LOOP(8, true, false); }
-    else if (nu == 16 && inner) { if (all4) LJMD_LOOP_ALL(16, true); else LJMD_LOOP(16, true, true); }
-    else if (nu == 16)    { if (all4) LJMD_LOOP_ALL(16, false); else LJMD_LOOP(16, true, false); }
-    else if (nu == 17 && inner) { if (all4) LJMD_LOOP_ALL(17, true); else LJMD_LOOP(17, true, true); }
-    else if (nu == 17)    { if (all4) LJMD_LOOP_ALL(17, false); else LJMD_LOOP(17, true, false); }
-    else if (nu == 18 && inner) { if (all4) LJMD_LOOP_ALL(18, true); else LJMD_LOOP(18, true, true); }
-    else if (nu == 18)    { if (all4) LJMD_LOOP_ALL(18, false); else LJMD_LOOP(18, true, false); }
-    else if (nu == 0 && inner) { if (all4) LJMD_LOOP_ALL(0, true); else LJMD_LOOP(0, true, true); }
-    else if (nu == 0)     { if (all4) LJMD_LOOP_ALL(0, false); else LJMD_LOOP(0, true, false); }
-    else if (nu == 24)    { if (all4) LJMD_LOOP_ALL(24, false); else LJMD_LOOP(24, true, false); }
-    else if (nu == 25)    { if (all4) LJMD_LOOP_ALL(25, false); else LJMD_LOOP(25, true, false); }
-    else if (nu == 26)    { if (all4) LJMD_LOOP_ALL(26, false); else LJMD_LOOP(26, true, false); }
-    else if (nu == 1)     { if (all4) LJMD_LOOP_ALL(1, false); else LJMD_LOOP(1, true, false); }
-    else if (nu == 2)     { if (all4) LJMD_LOOP_ALL(2, false); else LJMD_LOOP(2, true, false); }
-    else if (nu == 4)     { if (all4) LJMD_LOOP_ALL(4, false); else LJMD_LOOP(4, true, false); }
-    else                  { if (all4) LJMD_LOOP_ALL(7, false); else LJMD_LOOP(7, true, false); }
+    if (loop == 8 && inner) { if (all4) LJMD_LOOP_ALL(8, true); else LJMD_LOOP(8, true, true); }
+    else if (loop == 8)     { if (all4) LJMD_LOOP_ALL(8, false); else LJMD_LOOP(8, true, false); }
+#if !LJMD_FOLD_IMAGES
+    else if (loop == 16 && inner) { if (all4) LJMD_LOOP_ALL(16, true); else LJMD_LOOP(16, true, true); }
+    else if (loop == 16)    { if (all4) LJMD_LOOP_ALL(16, false); else LJMD_LOOP(16, true, false); }
+    else if (loop == 17 && inner) { if (all4) LJMD_LOOP_ALL(17, true); else LJMD_LOOP(17, true, true); }
+    else if (loop == 17)    { if (all4) LJMD_LOOP_ALL(17, false); else LJMD_LOOP(17, true, false); }
+    else if (loop == 18 && inner) { if (all4) LJMD_LOOP_ALL(18, true); else LJMD_LOOP(18, true, true); }
+    else if (loop == 18)    { if (all4) LJMD_LOOP_ALL(18, false); else LJMD_LOOP(18, true, false); }
+    else if (loop == 0 && inner) { if (all4) LJMD_LOOP_ALL(0, true); else LJMD_LOOP(0, true, true); }
+    else if (loop == 0)     { if (all4) LJMD_LOOP_ALL(0, false); else LJMD_LOOP(0, true, false); }
+    else if (loop == 1)     { if (all4) LJMD_LOOP_ALL(1, false); else LJMD_LOOP(1, true, false); }
+    else if (loop == 2)     { if (all4) LJMD_LOOP_ALL(2, false); else LJMD_LOOP(2, true, false); }
+    else if (loop == 4)     { if (all4) LJMD_LOOP_ALL(4, false); else LJMD_LOOP(4, true, false); }
+#endif
+    else if (loop == 24)    { if (all4) LJMD_LOOP_ALL(24, false); else LJMD_LOOP(24, true, false); }
+    else if (loop == 25)    { if (all4) LJMD_LOOP_ALL(25, false); else LJMD_LOOP(25, true, false); }
+    else if (loop == 26)    { if (all4) LJMD_LOOP_ALL(26, false); else LJMD_LOOP(26, true, false); }
+    else                    { if (all4) LJMD_LOOP_ALL(7, false); else LJMD_LOOP(7, true, false); }
 #undef LJMD_LOOP_ALL
 #undef LJMD_LOOP
 }
