@@ -8,6 +8,10 @@ OUT=gpurun_out/round2
 mkdir -p "$OUT"
 bash tools/collect_profiles.sh r02final > "$OUT/collect_final.log" 2>&1
 echo "[round2] final profiles done"
+# the same command WITH the liquid and sampled-segment legs: the forces-only instantiation pair_n3_kernel<3, 4, 1, false>
+# shows up as its own row beside <3, 4, 1, true>
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sampled_stats" -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/sampled_bench_under_rocprof.json" 2> "$OUT/sampled_stats.log"
+echo "[round2] sampled-segment stats done"
 python3 bench.py --mode mixed --steps 20 --warmup 3 --no-cpu-baseline > "$OUT/mixed_bench.json" 2> "$OUT/mixed_bench.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/mixed_stats" -o run -- python3 bench.py --mode mixed --steps 20 --warmup 3 --no-cpu-baseline --no-liquid > /dev/null 2> "$OUT/mixed_stats.log"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/mixed_pmc_valu" -o run -- python3 bench.py --mode mixed --steps 5 --warmup 1 --no-cpu-baseline --no-liquid > /dev/null 2> "$OUT/mixed_pmc_valu.log"
