@@ -281,9 +281,10 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (h->use_n3) {
             const dim3 grid((h->NGo + h->wg_waves - 1) / h->wg_waves, h->nslab_n);     // wg_waves row groups per workgroup
             N3Args na = n3_args(h);
-            // (below ~512 row groups per rank there are too few workgroups per XCD for the locality to matter: neutral
-            //  at 16384..65536 particles, -5 % at 8192)
-            na.xcd_remap = (h->xcd_remap > 0 && grid.x >= 512 && grid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
+            // (LJMD_N3_XCD_MIN_GROUPS, default 256 row groups per rank: with 4096 column tiles and 256 row groups -- rank
+            //  0 of 4 at n = 262144 -- the mapping still saves 4.7 % (tools/probe_rank.py), with 128 it is neutral, as it
+            //  is for single-rank systems of 16384..65536 particles)
+            na.xcd_remap = (h->xcd_remap > 0 && (int)grid.x >= h->xcd_min_groups && grid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
             LJMD_HIP(h, launch_pair_n3(na, grid, h->wg_waves, h->stream));            // all pairs, or the NEAR ones
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y * h->wg_waves;                                      // one partial per wave
@@ -298,7 +299,7 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
                 fa.flag_j = h->d_flag_j2;
                 fa.desc = h->d_desc_far;
                 fa.Q = h->Q2;
-                fa.xcd_remap = (h->xcd_remap > 0 && fgrid.x >= 512 && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
+                fa.xcd_remap = (h->xcd_remap > 0 && (int)fgrid.x >= h->xcd_min_groups && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
                 LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, h->stream));
                 nslab *= 2;
@@ -633,6 +634,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     // measured at n = 262144: chunks of 4 consecutive row groups per XCD -3 % pair-kernel time (19.8 -> 19.1 ms; 2: -1 %,
     // 8 / 16 / 32: +-0, one contiguous eighth per XCD: +10 %), -1.5 % at n = 131072 and 524288 (profiles/r02_xcd_remap_and_prefetch.txt)
     h->xcd_remap = std::max(0, env_int("LJMD_N3_XCD_REMAP", 4));
+    h->xcd_min_groups = std::max(1, env_int("LJMD_N3_XCD_MIN_GROUPS", 256));
     h->inject_failure_at = env_int("LJMD_INJECT_FAILURE_AT_STEP", -1);
     {
         const char *fx = std::getenv("LJMD_FORCE_EXCHANGE");

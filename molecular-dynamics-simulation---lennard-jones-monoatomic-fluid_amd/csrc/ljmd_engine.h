@@ -89,6 +89,7 @@ struct ljmd {
     double *d_fold = nullptr;     // [kFoldBlocks][2]
     unsigned *d_ticket = nullptr; // blocks-done counter of the kick kernel with the finalize folded in
     bool want_energy = true;      // false: the next force evaluations skip the energy sums (epot, d_epot, dd_epot = NaN)
+    int xcd_min_groups = 256;     // row groups per rank from which the XCD-aware mapping is used
     int xcd_remap = 0;            // LJMD_N3_XCD_REMAP: consecutive row groups per XCD chunk of the Newton-3 pair kernel (0 = plain mapping)
     bool fuse_small = true;       // LJMD_FUSE: boxes inside the drift kernel, finalize inside the kick kernel
     bool boxes_valid = false;     // d_bbox already holds the boxes of the current positions (written by the drift kernel)
