@@ -559,7 +559,7 @@ int upload_shard3(ljmd_t *h, double *dst, const double *x, const double *y, cons
 // ---------------------------------------------------------------------------
 extern "C" {
 
-const char *ljmd_version(void) { return "ljmd 0.4.0 gfx950"; }
+const char *ljmd_version(void) { return "ljmd 0.5.0 gfx950"; }
 
 int32_t ljmd_device_count(void)
 {
