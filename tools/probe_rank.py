@@ -23,7 +23,7 @@ def allgather(engines):
                 dst.memcpy(dst.exchange_buffer()[0] + 8 * off, sp + 8 * off, 8 * cnt, 3)
 
 
-for G in (1, 2, 4, 8):
+for G in [int(x) for x in os.environ.get("PROBE_G", "1,2,4,8").split(",")]:
     engines = [Engine(p, rank=g, n_ranks=G) for g in range(G)]
     for e in engines:
         e.force_buffers(True)
@@ -43,8 +43,8 @@ for G in (1, 2, 4, 8):
     eng.synchronize()
     wall = (time.perf_counter() - t0) / steps * 1e3
     prof = eng.profile_read()
-    if G == 1:
-        pair1 = prof["pair_ms"]
+    if G == 1 or "pair1" not in globals():
+        pair1 = prof["pair_ms"] * G
     print(f"G={G}: wall {wall:7.3f} ms/step | pair {prof['pair_ms']:7.3f} geometry {prof['geometry_ms']:6.3f} "
           f"drift(+resort) {prof['drift_ms']:6.3f} reduce+kick {prof['reduce_ms']:6.3f}  -> 1/G of the G=1 pair time would be {pair1 / G:6.3f}", flush=True)
     for e in engines:
