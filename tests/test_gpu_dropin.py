@@ -8,6 +8,7 @@
    literal "swap two files, link -lljmd" integration of INTEGRATION.md.  Compared with the
    files the pure reference wrote (tests/golden/ref_run_n108_*).
 """
+import os
 import shutil
 import subprocess
 from pathlib import Path
@@ -128,7 +129,6 @@ def test_thin_fortran_driver_several_ranks_from_one_process(tmp_path, tag, n_row
     engine with ljmd_create_multi; everything else in the driver is the single-GPU code.  Here the ranks share this
     box's one card (LJMD_DEVICES=0,0,...: peer-copy exchange); BASELINE config 1 against the reference's files with
     the same bounds as the single-engine run, and the binary trajectory against the single-engine run's."""
-    import os
     src = _workdir(tmp_path, tag)
     env = dict(os.environ, LJMD_GPUS=ranks, LJMD_DEVICES=",".join(["0"] * int(ranks)))
     out = subprocess.run([str(PKG / "bin" / "md_simulation_gpu")], cwd=tmp_path, check=True, capture_output=True,
@@ -193,6 +193,35 @@ def test_thin_fortran_pipeline_second_configuration(tmp_path):
     h, snaps = io_formats.read_rva(tmp_path / "outputs" / "one_run" / "rva.dat")
     assert h == dict(n=256, box_length=6.5, dt=0.002, output_interval=20, n_snapshots_expected=28)
     assert snaps.shape == (28, 4, 3, 256)
+
+
+@pytest.mark.parametrize("gpus", ["1", "2"])
+def test_thin_fortran_driver_sampled_segments_write_the_same_bytes(tmp_path, gpus):
+    """The production driver runs the steps between two samples with the forces-only pair kernel
+    (ljmd_enqueue_steps_sampled; the reference reads the energy sums only at md_simulation_program.f90:361).
+    N = 5324 (k = 11: Newton-3 kernel), 120 steps sampled every 30 after 30, init driver first (its warm-up uses
+    ljmd_verlet_steps with NULL outputs): LJMD_SAMPLED_STEPS=1 (default) and =0 (sums on every step) must write
+    byte-identical instantaneous_energies.dat, rva.dat and md_final_results.txt -- one process and LJMD_GPUS=2."""
+    (tmp_path / "inputs").mkdir()
+    (tmp_path / "outputs" / "one_run").mkdir(parents=True)
+    (tmp_path / "inputs" / "input_simulation_parameters.txt").write_text(
+        "k total_steps output_interval warmup_steps\n11 120 30 30\ndt L rc_over_L\n5.d-3 18.8d0 0.49d0\n"
+        "target_total_energy\n-2.2d4\n")
+    subprocess.run([str(PKG / "bin" / "md_initial_config_gpu")], cwd=tmp_path, check=True, timeout=300)
+    files = ("instantaneous_energies.dat", "rva.dat", "md_final_results.txt")
+    got = {}
+    for sampled in ("1", "0"):
+        for f in files:
+            (tmp_path / "outputs" / "one_run" / f).unlink(missing_ok=True)
+        env = dict(os.environ, LJMD_SAMPLED_STEPS=sampled, LJMD_GPUS=gpus, LJMD_DEVICES=",".join(["0"] * int(gpus)))
+        out = subprocess.run([str(PKG / "bin" / "md_simulation_gpu")], cwd=tmp_path, check=True, capture_output=True,
+                             text=True, timeout=300, env=env)
+        assert "N=5324" in out.stdout
+        got[sampled] = [(tmp_path / "outputs" / "one_run" / f).read_bytes() for f in files]
+    for f, a, b in zip(files, got["1"], got["0"]):
+        assert a == b, f
+    rows = io_formats.read_energies(tmp_path / "outputs" / "one_run" / "instantaneous_energies.dat")
+    assert rows.shape == (3, 6) and np.all(np.isfinite(rows))
 
 
 @pytest.mark.skipif(not (REF / "md_simulation_program_gpu").exists(),
