@@ -879,8 +879,9 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
     }
 }
 
+// 5 waves per SIMD (96 VGPRs; 20 spilled, none of them in the rotation loop): 11.73 -> 11.59 ms at n = 262144; 6: +-0, 8: +8 %
 template <bool ENERGY>
-__global__ __launch_bounds__(kTile, 4) void pair_n3_f32_kernel(N3Args a)
+__global__ __launch_bounds__(kTile, 5) void pair_n3_f32_kernel(N3Args a)
 {
     const int lane = threadIdx.x;                              // one wave per workgroup (see pair_n3_kernel)
     unsigned bx = blockIdx.x, by = blockIdx.y;                 // XCD-aware work mapping, as in pair_n3_kernel
