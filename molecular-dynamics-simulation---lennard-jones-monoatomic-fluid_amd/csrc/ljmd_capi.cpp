@@ -704,10 +704,11 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         // Measured at n = 262144 (profiles/r02_wg_waves_lds_combine.txt): the lock step costs more than the smaller
         // slab saves -- pair kernel 19.7 / 21.9 / 22.9 ms, slab reduction 0.63 / 0.41 / 0.29 ms for 1 / 2 / 4 --
         // so the default stays 1 and a larger value is chosen only where the column slab would not fit a budget
-        // (LJMD_SLAB_BUDGET_GB, default 24: e.g. n = 1 048 576 on ONE GPU, 52 GB -> 13 GB with 4).
+        // (LJMD_SLAB_BUDGET_GB, default 64 of the card's 288 GB: n = 1 048 576 on ONE GPU keeps W = 1 with a 52 GB slab --
+        // pair + reduction 287 ms against 303 ms with W = 4 and 13 GB -- and 2 097 152 particles run with W = 4, 52 GB).
         int wg = env_int("LJMD_N3_WG_WAVES", 0);
         if (wg != 1 && wg != 2 && wg != 4) {
-            const double budget = 1e9 * std::max(1, env_int("LJMD_SLAB_BUDGET_GB", 24));
+            const double budget = 1e9 * std::max(1, env_int("LJMD_SLAB_BUDGET_GB", 64));
             const double full = (double)h->NGo * (h->Dmax + 1) * rt * 3.0 * kTile * sizeof(double);
             wg = full <= budget ? 1 : full <= 2.0 * budget ? 2 : 4;
         }

@@ -541,10 +541,13 @@ def test_mixed_precision_mode_accuracy_and_drift(split, monkeypatch):
         Engine(init_params(4096, 17.2, 0.005, 8.0), precision_mode=_lib.PRECISION_FP32_FORCE)   # n too small
 
 
-def test_one_million_particles_single_gpu_indexing():
+@pytest.mark.parametrize("budget_gb", ["64", "24"])
+def test_one_million_particles_single_gpu_indexing(budget_gb, monkeypatch):
     """BASELINE config 4 size (N = 1 048 576 = 4 * 64^3, FCC + jitter) on ONE GPU: the column-side slab is
-    52 GB here (sized for 288 GB of HBM) and block offsets exceed 2^32 -- an indexing test.  Properties:
+    52 GB here (default budget 64 GB: sized for 288 GB of HBM) and block offsets exceed 2^32 -- an indexing test; with
+    a budget of 24 GB the engine chooses 4-wave workgroups that combine in LDS (13 GB).  Properties:
     total force = 0 (Newton 3), sampled rows against a direct numpy evaluation, two steps keep Etot."""
+    monkeypatch.setenv("LJMD_SLAB_BUDGET_GB", budget_gb)
     n = 1048576
     p, r, v = synthetic.make_config(n, lattice="fcc")
     with Engine(p) as eng:
