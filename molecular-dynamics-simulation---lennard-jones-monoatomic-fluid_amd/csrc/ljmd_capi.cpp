@@ -702,7 +702,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         // combined in LDS, so the column slab holds one block per (workgroup, column tile) -- wg_waves times less
         // memory and traffic.  Only for 4-tile row groups with plenty of them.
         // Measured at n = 262144 (profiles/r02_wg_waves_lds_combine.txt): the lock step costs more than the smaller
-        // slab saves -- pair kernel 19.7 / 21.9 / 22.9 ms, slab reduction 0.63 / 0.41 / 0.29 ms for 1 / 2 / 4 --
+        // slab saves -- pair kernel 18.0 / 18.8 / 19.9 ms, slab reduction 0.61 / 0.39 / 0.28 ms for 1 / 2 / 4 --
         // so the default stays 1 and a larger value is chosen only where the column slab would not fit a budget
         // (LJMD_SLAB_BUDGET_GB, default 64 of the card's 288 GB: n = 1 048 576 on ONE GPU keeps W = 1 with a 52 GB slab --
         // pair + reduction 287 ms against 303 ms with W = 4 and 13 GB -- and 2 097 152 particles run with W = 4, 52 GB).

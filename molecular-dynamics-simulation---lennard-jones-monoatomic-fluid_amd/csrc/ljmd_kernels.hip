@@ -303,6 +303,8 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
     // NU == 16 + a: every axis has a common image and only axis a's is non-zero: one subtraction more on that
     // axis, none on the others ((d - 0.0) == d, so this is the NU == 0 result bit for bit)
     // NU == 24 + a: axis a general, the two others with the common image n = 0 (same remark)
+    // With LJMD_FOLD_IMAGES (default) the common image is added to the column tile once per pass (n3_tile_pass) and only
+    // NU = 8, 24, 25, 26, 7 are instantiated; the shift-subtracting forms remain for -DLJMD_FOLD_IMAGES=0 builds.
     constexpr bool gx = (NU < 8 && (NU & 1)) || NU == 24, gy = (NU < 8 && (NU & 2)) || NU == 25,
                    gz = (NU < 8 && (NU & 4)) || NU == 26;
     constexpr bool px = NU == 8 || (NU >= 16 && NU != 16 && NU != 24), py = NU == 8 || (NU >= 16 && NU != 17 && NU != 25),
