@@ -268,15 +268,11 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (!h->use_n3) ga.mask_far = nullptr;
         if (!h->boxes_valid) LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
         h->boxes_valid = false;                    // good for this evaluation only
-        LJMD_HIP(h, launch_tile_mask(ga, h->stream));
-        if (h->use_n3) {    // pass descriptors of the fp64 Newton-3 kernel (from its own mask: the NEAR pairs in the mixed mode)
-            LJMD_HIP(h, launch_tile_class(ga, h->invL, h->rc2, h->S, h->NGo, h->d_desc, h->stream));
-            if (h->mode == LJMD_PRECISION_FP32_FORCE) {       // ... and of the fp32 far kernel, from the FAR mask
-                GeometryArgs gf = ga;
-                gf.mask = h->d_mask_far;
-                LJMD_HIP(h, launch_tile_class(gf, h->invL, h->rc2, h->S, h->NGo, h->d_desc_far, h->stream));
-            }
-        }
+        if (h->use_n3)      // tile-pair test + pass descriptors of the Newton-3 kernels in one launch (mixed mode: NEAR and FAR)
+            LJMD_HIP(h, launch_tile_class(ga, h->invL, h->rc2, h->S, h->NGo, h->d_desc,
+                                          h->mode == LJMD_PRECISION_FP32_FORCE ? h->d_desc_far : nullptr, h->stream));
+        else                // the gather kernel reads the bit mask
+            LJMD_HIP(h, launch_tile_mask(ga, h->stream));
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
         if (h->use_n3) {
             const dim3 grid((h->NGo + h->wg_waves - 1) / h->wg_waves, h->nslab_n);     // wg_waves row groups per workgroup

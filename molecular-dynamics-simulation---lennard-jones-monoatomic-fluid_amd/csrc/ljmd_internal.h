@@ -151,7 +151,8 @@ hipError_t launch_finalize(const FinalizeArgs &a, double *fold_scratch /* [2 * k
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s);
-hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc, hipStream_t s);
+hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc,
+                             unsigned *desc_far, hipStream_t s);
 
 // ljmd_sort.hip
 size_t sort_temp_bytes(int count);

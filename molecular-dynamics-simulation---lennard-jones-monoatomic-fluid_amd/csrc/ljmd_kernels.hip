@@ -1089,27 +1089,48 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
 // Same expressions as the former in-kernel classification; the row group's box is the union of its tiles' exact
 // boxes (= min / max over its 256 particles).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, double invL, double rc2, int S, unsigned *desc)
+__global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, double invL, double rc2, int S, unsigned *desc,
+                                                            unsigned *desc_far)
 {
     const int c = blockIdx.x * kBlock + threadIdx.x;           // column tile (global)
     const int Al = blockIdx.y;                                 // owned row group
     if (c >= a.T) return;
     const int RT = a.RT;
+    {   // only the (row group, column group) pairs the pair kernel visits: offset d = (B - A) mod NG in 0 .. NG / 2,
+        // the pair at exactly NG / 2 from its lower-numbered side (pair_n3_kernel's own_pair)
+        const int NG = a.T / RT, A = a.rank * (a.TB / RT) + Al, B = c / RT;
+        int d = B - A;
+        if (d < 0) d += NG;
+        if (!(d == 0 || 2 * d < NG || (2 * d == NG && A < B))) return;
+    }
     double glo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
     double ghi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
-    unsigned mb = 0;
+    const double *cbx = a.bbox + (size_t)c * kBoxStride;
+    unsigned mb = 0, mb_far = 0;
     for (int k = 0; k < RT; ++k) {
-        const int tl = RT * Al + k;
-        const double *bb = a.bbox + (size_t)(a.rank * a.TB + tl) * kBoxStride;
+        const int tl = RT * Al + k, I = a.rank * a.TB + tl;
+        const double *bb = a.bbox + (size_t)I * kBoxStride;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             glo[q] = fmin(glo[q], bb[q]);                      // fmin / fmax ignore the NaN of an all-padding tile
             ghi[q] = fmax(ghi[q], bb[3 + q]);
         }
-        const uint64_t w = a.mask[(size_t)tl * a.W + (c >> 6)];
-        mb |= (unsigned)((w >> (c & 63)) & 1ull) << k;
+        // the tile-pair test of tile_mask_kernel (same expressions): the bit is cleared only when the boxes prove every
+        // pair to be outside the cutoff; mixed precision splits the kept pairs into NEAR (fp64) and FAR (fp32)
+        double d2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double g = axis_gap(bb[q] - cbx[3 + q], bb[3 + q] - cbx[q], a.L);
+            d2 += g * g;
+        }
+        bool keep = !(d2 > a.rc2_skin) || (c == I);
+        if (desc_far) {
+            const bool near = (d2 <= a.rsplit2) || (c / RT == I / RT);
+            mb_far |= (unsigned)(keep && !near) << k;
+            keep = keep && near;
+        }
+        mb |= (unsigned)keep << k;
     }
-    const double *cbx = a.bbox + (size_t)c * kBoxStride;
     double sx = 0.0, sy = 0.0, sz = 0.0;
     const double lo[3] = {glo[0] - cbx[3], glo[1] - cbx[4], glo[2] - cbx[5]};
     const double hi[3] = {ghi[0] - cbx[0], ghi[1] - cbx[1], ghi[2] - cbx[2]};
@@ -1135,8 +1156,10 @@ __global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, doub
     }
     // shift = n L with |n| <= 2 (uniform_image): recover n exactly
     const int nx = (int)__builtin_rint(sx * invL), ny = (int)__builtin_rint(sy * invL), nzs = (int)__builtin_rint(sz * invL);
-    desc[(size_t)Al * a.T + c] = mb | ((unsigned)nu << 4) | ((unsigned)inner << 9) | ((unsigned)full << 10) |
-                                 ((unsigned)(nx + 2) << 11) | ((unsigned)(ny + 2) << 14) | ((unsigned)(nzs + 2) << 17);
+    const unsigned cls = ((unsigned)nu << 4) | ((unsigned)inner << 9) | ((unsigned)full << 10) |
+                         ((unsigned)(nx + 2) << 11) | ((unsigned)(ny + 2) << 14) | ((unsigned)(nzs + 2) << 17);
+    desc[(size_t)Al * a.T + c] = mb | cls;
+    if (desc_far) desc_far[(size_t)Al * a.T + c] = mb_far | cls;
 }
 
 // ---------------------------------------------------------------------------
@@ -1529,9 +1552,11 @@ hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc, hipStream_t s)
+hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc, unsigned *desc_far,
+                             hipStream_t s)
 {
-    hipLaunchKernelGGL(tile_class_kernel, dim3((a.T + kBlock - 1) / kBlock, NGo), dim3(kBlock), 0, s, a, invL, rc2, S, desc);
+    hipLaunchKernelGGL(tile_class_kernel, dim3((a.T + kBlock - 1) / kBlock, NGo), dim3(kBlock), 0, s, a, invL, rc2, S, desc,
+                       desc_far);
     return hipGetLastError();
 }
 
