@@ -677,7 +677,8 @@ def test_sampled_segments_skip_the_energy_sums_and_nothing_else(n, mode, devices
     with Engine(p, **kw) as chk:
         chk.set_state(*fin["r"], *fin["v"])
         # (a fresh engine sorts the particles into another slot order: same sums, other rounding)
-        assert np.allclose(np.array(chk.compute_forces()), np.array(sc), rtol=1e-12, atol=0.0)
+        # (fp64: the virial is a difference of two large sums; mixed: the far sums are accumulated in fp32 per tile pass)
+        assert np.allclose(np.array(chk.compute_forces()), np.array(sc), rtol=1e-11 if mode == 0 else 1e-7, atol=0.0)
     assert np.array_equal(got[1], want[1])                       # ekin, every step
     assert np.array_equal(got[:, -1], want[:, -1])               # the sampled step, all four
     assert np.array_equal(got2[:, 0], want2[:, -1])
