@@ -11,6 +11,7 @@ host wait for the snapshot transfer and write the files.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from pathlib import Path
 
@@ -71,9 +72,12 @@ def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunR
                 nxt += ctl.output_interval
             return min(max(min(nxt, ctl.total_steps) - from_step, 0), MAX_PENDING_STEPS)
 
-        # software pipeline: the GPU runs the next segment while the host writes this sample
+        # software pipeline: the GPU runs the next segment while the host writes this sample; only the last step of a
+        # segment is read below (:361), so the steps in between run the forces-only pair kernel (LJMD_SAMPLED_STEPS=0:
+        # energy sums on every step, as in the Fortran driver)
+        sampled = os.environ.get("LJMD_SAMPLED_STEPS", "1") != "0"
         count = segment_length(step)
-        eng.enqueue_steps(count)
+        eng.enqueue_steps(count, sampled=sampled)
         while step < ctl.total_steps:
             epot, ekin, d_epot, dd_epot = eng.collect_steps(count)
             for _ in range(count):
@@ -84,7 +88,7 @@ def run_md_simulation(root_dir, device: int = 0, write_rva: bool = True) -> RunR
                 eng.snapshot_begin()
             count = segment_length(step)
             if count > 0:
-                eng.enqueue_steps(count)
+                eng.enqueue_steps(count, sampled=sampled)
             if sample_now:
                 e, k = float(epot[-1]), float(ekin[-1])
                 temp, press = acc.push(e, k, d_epot[-1], dd_epot[-1])                   # :371-372
