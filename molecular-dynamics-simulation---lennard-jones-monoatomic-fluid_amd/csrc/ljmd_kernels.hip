@@ -630,7 +630,8 @@ __device__ __forceinline__ void tile_to_lds_async(const N3Args &a, int lane, int
 
 // Measured (profiles/r02_xcd_remap_and_prefetch.txt): with the next tile prefetched the pair kernel takes 19.16 ms,
 // without 19.05-19.26 ms -- the two other waves of a SIMD already hide the tile fetch.  Parity-green
-// (make EXTRA=-DLJMD_PREFETCH=1), kept out of the default build.
+// (make EXTRA="-DLJMD_PREFETCH=1 -DLJMD_FOLD_IMAGES=0": the DMA bypasses the registers where the image fold happens), kept out of
+// the default build.
 #ifndef LJMD_PREFETCH
 #define LJMD_PREFETCH 0
 #endif
