@@ -356,6 +356,22 @@ def main() -> None:
                 line["roofline"].update({"valu_issue_frac": k["valu_issue_frac"],
                                          "valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"],
                                          "valu_source": f"profiles/{valu.name}"})
+        # executed fp64 instruction mix of the pair kernel (PMC passes 5 / 6 of tools/collect_profiles.sh): the flop the
+        # kernel really executes per launch (exec-masked lanes included) over the LIVE kernel time, beside the
+        # algorithmic figure above; LDS bank conflicts of the parked column tiles
+        mixf = committed("final_pmc_instruction_mix.json")
+        if world == 1 and n == N_PARTICLES and args.mode == "fp64" and mixf and force_ms > 0:
+            kernels = json.loads(mixf.read_text())["kernels"]
+            hits = headline_instances(kernels, kernel_name)
+            k = max(hits, key=lambda val: val.get("executed_fp64_flop", 0.0)) if hits else {}
+            if k.get("executed_fp64_flop"):
+                ex = k["executed_fp64_flop"] / (force_ms * 1e-3) / 1e12
+                line["roofline"].update({"executed_fp64_tflops": ex, "executed_fp64_frac_of_peak": ex / FP64_VALU_PEAK_TFLOPS,
+                                         "fp64_wave_instructions": {x: k.get("SQ_INSTS_VALU_" + x) for x in
+                                                                    ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64")},
+                                         "lds_wave_instructions": k.get("SQ_INSTS_LDS"),
+                                         "lds_bank_conflict_cycles": k.get("SQ_LDS_BANK_CONFLICT"),
+                                         "mix_source": f"profiles/{mixf.name}"})
         # K1 by the profiler's clock (a HIP-event interval around a 9 us kernel is mostly event overhead)
         stats = committed("final_kernel_stats.csv")
         if world == 1 and n == N_PARTICLES and stats and "roofline_hbm_kernel" in line:

@@ -90,6 +90,37 @@ if valu_dir.exists() and list(valu_dir.rglob("*counter_collection.csv")):
     for k, m in vk.items():
         if k.startswith("ljmdk::pair_n3_kernel<"):
             print(k, "SQ_INSTS_VALU %.4g" % m.get("SQ_INSTS_VALU", 0), "valu_issue_frac %.3f" % m.get("valu_issue_frac", 0))
+# ---- instruction mix / LDS evidence (optional passes 5 and 6) ----
+mix = defaultdict(lambda: defaultdict(list))
+for sub in ("pmc_mix_fp64", "pmc_mix_lds"):
+    d = out / sub
+    if d.exists() and list(d.rglob("*counter_collection.csv")):
+        for r in csv.DictReader(open(find(sub, "counter_collection.csv"))):
+            mix[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if mix:
+    mk = {}
+    for name, c in mix.items():
+        if not name.startswith("ljmdk::"):
+            continue
+        m = {k: sum(v) / len(v) for k, v in c.items()}
+        if "SQ_INSTS_VALU_FMA_F64" in m:
+            m["fp64_arith_wave_instructions"] = sum(m.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+                                                                           "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+            # executed flop per launch: 64 lanes per wave-instruction (lanes switched off by EXEC included), FMA = 2
+            m["executed_fp64_flop"] = 64.0 * (m.get("SQ_INSTS_VALU_ADD_F64", 0.0) + m.get("SQ_INSTS_VALU_MUL_F64", 0.0) +
+                                              2.0 * m.get("SQ_INSTS_VALU_FMA_F64", 0.0) + m.get("SQ_INSTS_VALU_TRANS_F64", 0.0))
+        mk[name] = m
+    mdoc = {"command": "rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 "
+                       "SQ_INSTS_VALU | SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM "
+                       "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -- python3 bench.py --steps 5 --warmup 1 "
+                       "--no-cpu-baseline --no-liquid (two passes)",
+            "units": "wave-instructions per launch (means); executed_fp64_flop = 64 x (ADD + MUL + 2 FMA + TRANS)",
+            "kernels": mk}
+    (out / "pmc_instruction_mix.json").write_text(json.dumps(mdoc, indent=1))
+    for k, m in mk.items():
+        if k.startswith("ljmdk::pair_n3_kernel<"):
+            print(k, "fp64 add/mul/fma/trans %.3g/%.3g/%.3g/%.3g" % tuple(m.get("SQ_INSTS_VALU_" + x, 0) for x in ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64")),
+                  "LDS instr %.3g bank conflicts %.3g" % (m.get("SQ_INSTS_LDS", 0), m.get("SQ_LDS_BANK_CONFLICT", 0)))
 for k in kernels:
     if k.startswith(("ljmdk::pair_n3_kernel<", "ljmdk::drift_kick_kernel<", "ljmdk::reduce_forces_kernel<")):
         print(k, f"{kernels[k]['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch")

@@ -8,6 +8,7 @@ cp $F/bench_under_rocprof.json profiles/r02_final_bench_under_rocprof.json
 cp $F/kernel_stats.csv profiles/r02_final_kernel_stats.csv
 cp $F/pmc_hbm_traffic.json profiles/r02_final_pmc_hbm_traffic.json
 cp $F/pmc_valu.json profiles/r02_final_pmc_valu.json
+cp $F/pmc_instruction_mix.json profiles/r02_final_pmc_instruction_mix.json
 # mixed mode: its own --stats and VALU passes (pmc_summary.py wants the traffic passes too: the fp64 ones stand in and
 # their summary is not copied)
 T=$(mktemp -d)
