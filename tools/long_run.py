@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Energy conservation over a long NVE run at the bench size (north-star: 10 000 steps at N = 262144):
 total energy, temperature, pressure and total momentum in blocks of 500 steps, fp64 engine.
-Prints one JSON line per block (progress) and a summary line.  LONG_N, LONG_STEPS, LONG_MODE=fp64|mixed."""
+Prints one JSON line per block (progress) and a summary line.  LONG_N, LONG_STEPS, LONG_MODE=fp64|mixed, LONG_LATTICE=auto|sc|fcc."""
 import json
 import os
 import sys
@@ -19,7 +19,7 @@ n = int(os.environ.get("LONG_N", "262144"))
 steps = int(os.environ.get("LONG_STEPS", "10000"))
 mode = os.environ.get("LONG_MODE", "fp64")
 block = 500
-p, r, v = synthetic.make_config(n)
+p, r, v = synthetic.make_config(n, lattice=os.environ.get("LONG_LATTICE", "auto"))
 with Engine(p, precision_mode=_lib.PRECISION_FP32_FORCE if mode == "mixed" else _lib.PRECISION_FP64) as eng:
     eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
     e0 = eng.compute_forces()[0]
