@@ -52,6 +52,8 @@ GeometryArgs geometry_args(ljmd_t *h)
     GeometryArgs a;
     a.pos = h->d_pos;
     a.bbox = h->d_bbox;
+    a.pos_tc = h->use_n3 ? h->d_pos_tc : nullptr;
+    a.invL = h->invL;
     a.mask = h->d_mask;
     a.P = h->P;
     a.G = h->G;
@@ -70,7 +72,7 @@ GeometryArgs geometry_args(ljmd_t *h)
 N3Args n3_args(ljmd_t *h)
 {
     N3Args a;
-    a.pos = h->d_pos;
+    a.pos = h->d_pos_tc;       // every tile in one periodic image (tile_boxes_kernel / the drift kernel's fused form)
     a.mask = h->d_mask;
     a.bbox = h->d_bbox;
     a.desc = h->d_desc;
@@ -108,6 +110,7 @@ IntegrateArgs integrate_args(ljmd_t *h)
     a.a = h->d_a;
     a.fsum = needs_force_exchange(h) ? h->d_frecv : h->d_fpart;
     a.bbox = nullptr;
+    a.pos_tc = nullptr;
     a.ticket = nullptr;
     a.ke_part = h->d_ke_part;
     a.rows = h->P;
@@ -405,7 +408,10 @@ int enqueue_drift(ljmd_t *h, EventSet *q)
         // (only where a launch matters: at n = 262144 the six wave reductions cost the HBM-bound kernel more -- 8.0 ->
         // 11.5 us -- than the 5 us boxes kernel they replace)
         h->boxes_valid = h->fuse_small && h->G == 1 && h->n <= 65536 && !resort_now && fast_path_ok(h);
-        if (h->boxes_valid) ia.bbox = h->d_bbox;
+        if (h->boxes_valid) {
+            ia.bbox = h->d_bbox;
+            ia.pos_tc = h->use_n3 ? h->d_pos_tc : nullptr;
+        }
         LJMD_HIP(h, launch_drift_kick(ia, 0, h->stream));
     }
     h->positions_compact = true;  // freshly wrapped into [0, L]
@@ -471,7 +477,7 @@ void release(ljmd_t *h)
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv, h->d_fall,
                    h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket,
-                   h->d_desc, h->d_desc_far};
+                   h->d_desc, h->d_desc_far, h->d_pos_tc};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -756,6 +762,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
             LJMD_HIP(h, hipMalloc(&h->d_flag_j, n_blk));
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, n_blk, h->stream));
             LJMD_HIP(h, hipMalloc(&h->d_desc, (size_t)h->NGo * h->T * sizeof(unsigned)));
+            LJMD_HIP(h, hipMalloc(&h->d_pos_tc, P3 * h->G));
         }
         if (mixed) {
             LJMD_HIP(h, hipMalloc(&h->d_mask_far, (size_t)h->TB * h->W * sizeof(uint64_t)));

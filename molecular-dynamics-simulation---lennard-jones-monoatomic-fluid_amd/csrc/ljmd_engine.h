@@ -98,6 +98,7 @@ struct ljmd {
     unsigned *d_ring_pos = nullptr;
     double *d_bbox = nullptr;     // [T][kBoxStride]
     uint64_t *d_mask = nullptr;   // [TB][W]
+    double *d_pos_tc = nullptr;   // [G][3][P] tile-coherent copy of d_pos for the Newton-3 kernels (tile_boxes_kernel)
     unsigned *d_desc = nullptr;   // [NGo][T] pass descriptors of the Newton-3 kernel (tile_class_kernel)
     unsigned *d_desc_far = nullptr;   // same for the fp32 far kernel of the mixed mode (from mask_far)
     // sorting scratch

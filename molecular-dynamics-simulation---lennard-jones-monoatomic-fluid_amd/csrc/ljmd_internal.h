@@ -77,6 +77,7 @@ struct IntegrateArgs {
     int P;
     double L, invL, dt, dt_half, dt_sq_half;
     double *bbox;           // drift kernel, single rank: also emit the tile bounding boxes [P / 64][kBoxStride] (else NULL)
+    double *pos_tc;         // ... and, on the Newton-3 path, the tile-coherent copy of the new positions [3][P] (else NULL)
     unsigned *ticket;       // kick kernel with the finalize folded in: blocks-done counter (else NULL)
 };
 
@@ -110,12 +111,14 @@ struct FinalizeArgs {
 struct GeometryArgs {
     const double *pos;      // exchange buffer
     double *bbox;           // [T][kBoxStride]
+    double *pos_tc;         // Newton-3 path: tile-coherent copy of pos, same layout (else NULL): every tile's particles in the
+                            // periodic image nearest to the tile's first particle; bbox then bounds THOSE coordinates
     uint64_t *mask;         // [TB][W]
     uint64_t *mask_far;     // mixed precision only (else NULL): [TB][W] tile pairs evaluated in fp32;
                             // `mask` then holds only the NEAR pairs (box distance <= r_split, or same row group)
     int P, G, rank, TB, T, W;
     int RT;                 // tiles per Newton-3 row group (same-group pairs always count as NEAR)
-    double L, rc2_skin;     // rc^2 * (1 + 1e-10): skip only when provably outside
+    double L, invL, rc2_skin;   // rc^2 * (1 + 1e-10): skip only when provably outside
     double rsplit2;         // r_split^2
 };
 

@@ -1008,14 +1008,40 @@ __global__ __launch_bounds__(kTile, 5) void pair_n3_f32_kernel(N3Args a)
 // Geometry pre-pass 1: exact axis-aligned bounding box of every 64-slot tile of the
 // exchange buffer (NaN padding ignored).  One wave per tile; reads 24 N bytes.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_first(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// the periodic image of x nearest to the anchor; x itself (bit for bit) when |x - anchor| < L / 2
+__device__ __forceinline__ double tile_frame(double x, double anchor, double L, double invL)
+{
+    return fma(-L, __builtin_rint((x - anchor) * invL), x);
+}
+
 __global__ __launch_bounds__(kBlock) void tile_boxes_kernel(GeometryArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (t >= a.T) return;
     const int g = t / a.TB, tl = t - g * a.TB;
-    const double *b = a.pos + (size_t)g * 3 * a.P + (size_t)tl * kTile + lane;
-    const double x = b[0], y = b[a.P], z = b[2 * (size_t)a.P];
+    const size_t o0 = (size_t)g * 3 * a.P + (size_t)tl * kTile + lane;
+    const double *b = a.pos + o0;
+    double x = b[0], y = b[a.P], z = b[2 * (size_t)a.P];
+    if (a.pos_tc) {
+        // Tile frame (Newton-3 path): a particle that has just crossed a face of the box sits at the other end of the
+        // wrapped interval, and a plain bounding box of its tile would span the whole box on that axis -- the tile would
+        // meet every column on that axis, lose its common-image and INNER passes, and (mixed mode) its fp32 offsets would
+        // be ~L/2.  The pair kernels therefore read a copy in which every particle of a tile is in the periodic image
+        // nearest to the tile's first particle (x' = x - L rint((x - x0) / L): x itself unless the tile straddles a
+        // face); the box bounds those coordinates.  Forces depend on coordinate differences modulo L only.
+        x = tile_frame(x, wave_first(x), a.L, a.invL);
+        y = tile_frame(y, wave_first(y), a.L, a.invL);
+        z = tile_frame(z, wave_first(z), a.L, a.invL);
+        double *c = a.pos_tc + o0;
+        c[0] = x; c[a.P] = y; c[2 * (size_t)a.P] = z;
+    }
     const double lx = wave_min(x), ly = wave_min(y), lz = wave_min(z);
     const double hx = wave_max(x), hy = wave_max(y), hz = wave_max(z);
     if (lane == 0) {
@@ -1199,6 +1225,13 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
     if constexpr (BOXES && PHASE != 2) {
         // single rank: the wave holds exactly one tile -- emit its bounding box here (same values, same
         // reductions as tile_boxes_kernel) and save that launch
+        if (a.pos_tc) {                                       // Newton-3 path: tile frame, as in tile_boxes_kernel
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                rn[ax] = tile_frame(rn[ax], wave_first(rn[ax]), a.L, a.invL);
+                a.pos_tc[(size_t)ax * a.P + i] = rn[ax];
+            }
+        }
         const double lx = wave_min(rn[0]), ly = wave_min(rn[1]), lz = wave_min(rn[2]);
         const double hx = wave_max(rn[0]), hy = wave_max(rn[1]), hz = wave_max(rn[2]);
         if ((threadIdx.x & 63) == 0) {
