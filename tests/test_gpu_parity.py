@@ -110,6 +110,38 @@ def test_production_kernel_configuration_vs_oracle_n32768(oracle):
     assert np.abs(a - a_o).max() <= REL_ACCEL * np.abs(a_o).max()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tiles_that_straddle_a_box_face_vs_oracle_n32768(oracle, mode, monkeypatch):
+    """Between two re-sorts particles cross the faces of the box and reappear at the other end of the wrapped interval
+    while they stay in their tile.  The Newton-3 kernels read a tile-coherent copy of the positions (every tile in the
+    periodic image of its first particle, tile_boxes_kernel) so that such a tile keeps a compact box.  12 steps without
+    any re-sort from a start shifted so that a lattice plane lies on every face, then the resident accelerations and
+    scalars against the pinned oracle evaluated at the engine's own (wrapped) positions -- fp64 and mixed precision."""
+    monkeypatch.setenv("LJMD_RESORT_EVERY", "1000")
+    n = 32768
+    p, r, v = synthetic.make_config(n, seed=5)
+    L = p.box_length
+    r = (r + 0.5 * L / 32.0) % L                     # simple-cubic planes (spacing L / 32) onto the faces
+    with Engine(p, precision_mode=mode) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        eng.compute_forces()
+        e, k, d, dd = eng.verlet_steps(12)
+        st = eng.get_state(("r", "ru", "a"))
+    rr, ru, a = np.stack(st["r"]), np.stack(st["ru"]), np.stack(st["a"])
+    crossed = np.count_nonzero(np.abs(rr - ru) > 0.5 * L)        # wrapped != unwrapped: went through a face
+    assert crossed > 500, crossed                                # ... spread over most of the 96 face tiles
+    assert rr.min() >= 0.0 and rr.max() < L
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, rr[0].copy(), rr[1].copy(), rr[2].copy())
+    a_o = np.stack([ax, ay, az])
+    if mode == 0:
+        assert rel(e[-1], e_o) <= 1e-12 and rel(d[-1], d_o) <= 1e-12 and rel(dd[-1], dd_o) <= 1e-12
+        assert np.abs(a - a_o).max() <= REL_ACCEL * np.abs(a_o).max()
+    else:       # the bounds of the mixed-precision parity test at n = 262144
+        assert rel(e[-1], e_o) <= 5e-9 and rel(d[-1], d_o) <= 5e-9 and rel(dd[-1], dd_o) <= 5e-9
+        assert np.abs(a - a_o).max() <= 1e-9 * np.abs(a_o).max()
+
+
 @pytest.mark.parametrize("n,rc_over_L,n3", [(4096, 0.15, True), (4096, 0.15, False), (32768, 0.08, True), (2500, 0.30, True)])
 def test_short_cutoff_most_tile_pairs_skipped(oracle, n, rc_over_L, n3, monkeypatch):
     """rc well below L/2 (allowed by the reference: 0 < rc_over_L <= 0.5): most tile pairs are masked
