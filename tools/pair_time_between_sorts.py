@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Pair-kernel time of every single step over three re-sort intervals in the equilibrated liquid (n = 262144): does the
+"""Pair-kernel time of every single step over three re-sort intervals (n = 262144) after PROBE_ADVANCE steps (default 400: the equilibrated liquid; 3: the bench's timed region): does the
 kernel slow down between two k-d sorts (tiles loosening as the particles move)?  Measurement tool."""
+import os
 import sys
 from pathlib import Path
 
@@ -12,7 +13,7 @@ p, r, v = synthetic.make_config(262144)
 with Engine(p) as eng:
     eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
     eng.compute_forces()
-    eng.advance(400)
+    eng.advance(int(os.environ.get("PROBE_ADVANCE", "400")))
     rows = []
     for s in range(30):
         eng.profile_enable(True)
