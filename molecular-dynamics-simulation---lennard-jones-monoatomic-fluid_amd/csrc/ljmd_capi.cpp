@@ -111,6 +111,7 @@ IntegrateArgs integrate_args(ljmd_t *h)
     a.fsum = needs_force_exchange(h) ? h->d_frecv : h->d_fpart;
     a.bbox = nullptr;
     a.pos_tc = nullptr;
+    a.RT = std::max(1, h->rt);
     a.ticket = nullptr;
     a.ke_part = h->d_ke_part;
     a.rows = h->P;

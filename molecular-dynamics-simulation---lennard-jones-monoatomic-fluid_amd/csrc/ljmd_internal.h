@@ -78,6 +78,7 @@ struct IntegrateArgs {
     double L, invL, dt, dt_half, dt_sq_half;
     double *bbox;           // drift kernel, single rank: also emit the tile bounding boxes [P / 64][kBoxStride] (else NULL)
     double *pos_tc;         // ... and, on the Newton-3 path, the tile-coherent copy of the new positions [3][P] (else NULL)
+    int RT;                 // tiles per Newton-3 row group (the frame of pos_tc is per group)
     unsigned *ticket;       // kick kernel with the finalize folded in: blocks-done counter (else NULL)
 };
 

@@ -1034,11 +1034,14 @@ __global__ __launch_bounds__(kBlock) void tile_boxes_kernel(GeometryArgs a)
         // wrapped interval, and a plain bounding box of its tile would span the whole box on that axis -- the tile would
         // meet every column on that axis, lose its common-image and INNER passes, and (mixed mode) its fp32 offsets would
         // be ~L/2.  The pair kernels therefore read a copy in which every particle of a tile is in the periodic image
-        // nearest to the tile's first particle (x' = x - L rint((x - x0) / L): x itself unless the tile straddles a
+        // nearest to the first particle of its row group (x' = x - L rint((x - x0) / L): x itself unless the group straddles a
         // face); the box bounds those coordinates.  Forces depend on coordinate differences modulo L only.
-        x = tile_frame(x, wave_first(x), a.L, a.invL);
-        y = tile_frame(y, wave_first(y), a.L, a.invL);
-        z = tile_frame(z, wave_first(z), a.L, a.invL);
+        // (the anchor is the first particle of the tile's ROW GROUP: the RT tiles of a group share one frame, so that
+        //  the group's box -- the union that decides the image class and INNER of its passes -- stays compact too)
+        const double *g0 = a.pos + (size_t)g * 3 * a.P + (size_t)(tl / a.RT) * a.RT * kTile;
+        x = tile_frame(x, g0[0], a.L, a.invL);
+        y = tile_frame(y, g0[a.P], a.L, a.invL);
+        z = tile_frame(z, g0[2 * (size_t)a.P], a.L, a.invL);
         double *c = a.pos_tc + o0;
         c[0] = x; c[a.P] = y; c[2 * (size_t)a.P] = z;
     }
@@ -1226,9 +1229,18 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
         // single rank: the wave holds exactly one tile -- emit its bounding box here (same values, same
         // reductions as tile_boxes_kernel) and save that launch
         if (a.pos_tc) {                                       // Newton-3 path: tile frame, as in tile_boxes_kernel
+            // the block's four waves are four consecutive tiles = whole row groups (RT = 1, 2 or 4): the anchor of a
+            // group, its first tile's first particle, comes from the neighbouring wave through LDS
+            __shared__ double anchor[kWavesPerBlock][3];
+            const int w = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) {
+                anchor[w][0] = rn[0]; anchor[w][1] = rn[1]; anchor[w][2] = rn[2];
+            }
+            __syncthreads();
+            const int w0 = (w / a.RT) * a.RT;
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-                rn[ax] = tile_frame(rn[ax], wave_first(rn[ax]), a.L, a.invL);
+                rn[ax] = tile_frame(rn[ax], anchor[w0][ax], a.L, a.invL);
                 a.pos_tc[(size_t)ax * a.P + i] = rn[ax];
             }
         }

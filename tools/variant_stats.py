@@ -22,7 +22,8 @@ names = {8: "no image", 16: "common image, x only", 17: "common image, y only", 
 with Engine(p) as eng:
     eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
     eng.compute_forces()
-    for label, steps in (("t = 0 (jittered lattice)", 0), ("after 300 steps (liquid)", 300)):
+    for label, steps in (("t = 0 (jittered lattice)", 0), ("after 300 steps (liquid, right after a re-sort)", 300),
+                         ("after 309 steps (liquid, 9 steps after the re-sort)", 9)):
         if steps:
             eng.verlet_steps(steps)
         lib.ljmd_debug_variant_stats(buf, 1)
