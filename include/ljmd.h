@@ -247,6 +247,10 @@ int ljmd_allgather_positions(ljmd_t *h);
 /* Ranks RCCL itself reports for this handle's communicator (ncclCommCount); 0 = no communicator.
  * bench.py prints it so that a multi-GPU line proves the collective ran over all ranks. */
 int32_t ljmd_comm_size(const ljmd_t *h);
+/* multi-device handle: ownership migrations done so far (LJMD_MULTI_MIGRATE_EVERY, default every 2000 steps: the particles
+ * are dealt out to the ranks again by position, because an index-range shard diffuses out of its slab in a liquid; the
+ * caller's arrays keep their order); 0 for any other handle */
+int32_t ljmd_multi_migrations(const ljmd_t *h);
 /* Copy on the handle's stream, then wait: kind 1 = host->device, 2 = device->host, 3 = device->device.
  * For callers that stage the exchange / force buffers themselves (host-staged fallback, tests). */
 int ljmd_memcpy(ljmd_t *h, void *dst, const void *src, int64_t bytes, int32_t kind);

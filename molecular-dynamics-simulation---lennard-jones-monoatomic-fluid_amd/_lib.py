@@ -56,6 +56,7 @@ PROTOTYPES = {
     "ljmd_get_state": (C.c_int, [C.c_void_p] + [c_double_p] * 12),
     "ljmd_compute_forces": (C.c_int, [C.c_void_p] + [c_double_p] * 3),
     "ljmd_verlet_steps": (C.c_int, [C.c_void_p, C.c_int32] + [c_double_p] * 4),
+    "ljmd_multi_migrations": (C.c_int32, [C.c_void_p]),
     "ljmd_enqueue_steps": (C.c_int, [C.c_void_p, C.c_int32]),
     "ljmd_enqueue_steps_sampled": (C.c_int, [C.c_void_p, C.c_int32]),
     "ljmd_set_observables": (C.c_int, [C.c_void_p, C.c_int32]),

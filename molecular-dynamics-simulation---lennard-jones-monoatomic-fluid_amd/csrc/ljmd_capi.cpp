@@ -1343,6 +1343,11 @@ int ljmd_comm_init(ljmd_t *h, const char *id)
     return LJMD_OK;
 }
 
+int32_t ljmd_multi_migrations(const ljmd_t *h)
+{
+    return (h && h->multi) ? ljmdm::migrations(h) : 0;
+}
+
 int32_t ljmd_comm_size(const ljmd_t *h)
 {
     if (h && h->multi) return ljmdm::comm_size(h);

@@ -27,6 +27,13 @@ struct ljmd_multi {
     std::vector<ncclComm_t> comm;
     std::vector<hipEvent_t> ev_pos, ev_force;     // copy exchange: "rank g's block is ready"
     std::vector<double> recs;                     // [G][kPartialStride] scratch of one step
+    // Ownership migration.  The ranks own index ranges of the ENGINE order; `owner[k]` = the caller's index of the particle
+    // at engine index k (identity until the first migration).  Every `migrate_every` steps the particles are dealt out again
+    // by position -- rank g takes the g-th n / G of them along the longest axis -- because a fixed SET of particles diffuses
+    // out of the slab it filled at t = 0 and the rank's 64-particle tiles grow (profiles/r02_shard_mixing_long_run.txt).
+    std::vector<int32_t> owner;
+    int migrate_every = 0, steps_since_migration = 0, migrations = 0;
+    std::vector<double> stage[12];                // engine-order staging of r, ru, v, a (x, y, z each)
 };
 
 namespace ljmdm {
@@ -50,6 +57,15 @@ int child_failed(ljmd_t *h, const ljmd_t *c, int code)
         const int rc__ = (expr);                                 \
         if (rc__ != LJMD_OK) return child_failed((h), (c), rc__); \
     } while (0)
+
+// caller order -> engine order (in[] = 3 caller arrays; out = m->stage[base .. base + 2])
+void to_engine_order(ljmd_multi *m, int n, const double *const in[3], int base)
+{
+    for (int a = 0; a < 3; ++a) {
+        m->stage[base + a].resize(n);
+        for (int k = 0; k < n; ++k) m->stage[base + a][k] = in[a][m->owner[k]];
+    }
+}
 
 int exchange_positions(ljmd_t *h)
 {
@@ -215,6 +231,15 @@ int create(ljmd_t **out, int32_t n, double box_length, double dt, double rc, int
     // the parent carries the parameters the scalar combination needs (tail constants) and what callers query
     const ljmd_t *e0 = m->eng[0];
     h->n = n; h->G = n_gpus; h->S = e0->S; h->P = e0->P; h->mode = precision_mode;
+    m->owner.resize(n);
+    for (int k = 0; k < n; ++k) m->owner[k] = k;
+    // LJMD_MULTI_MIGRATE_EVERY: steps between two ownership migrations (0 = never).  Default 2000: at n = 65536 and 8
+    // ranks the step rate falls by 1 % per 1000 steps without it (tools/shard_mixing_probe.py) and one migration costs
+    // about as much as 50 steps there
+    {
+        const char *me = std::getenv("LJMD_MULTI_MIGRATE_EVERY");
+        m->migrate_every = me && *me ? std::max(0, std::atoi(me)) : 2000;
+    }
     h->L = e0->L; h->invL = e0->invL; h->volume = e0->volume; h->rc = e0->rc; h->rc2 = e0->rc2;
     h->dt = e0->dt; h->dt_half = e0->dt_half; h->dt_sq_half = e0->dt_sq_half;
     h->tail_e = e0->tail_e; h->tail_d = e0->tail_d; h->tail_dd = e0->tail_dd;
@@ -284,6 +309,8 @@ int set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz, c
               const double *vz)
 {
     ljmd_multi *m = h->multi;
+    for (int k = 0; k < h->n; ++k) m->owner[k] = k;         // a new state starts from the caller's index ranges
+    m->steps_since_migration = 0;
     for (ljmd_t *e : m->eng) {
         // after a batch that failed half-way the ranks are a phase apart: every rank drains its stream and
         // re-synchronises its record ring with its own device count (ljmd_set_state on a poisoned engine)
@@ -298,25 +325,48 @@ int set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz, c
 
 int set_accel(ljmd_t *h, const double *ax, const double *ay, const double *az)
 {
-    for (ljmd_t *e : h->multi->eng) LJMD_CHILD(h, e, ljmd_set_accel(e, ax, ay, az));
+    ljmd_multi *m = h->multi;
+    const double *in[3] = {ax, ay, az};
+    to_engine_order(m, h->n, in, 9);
+    for (ljmd_t *e : m->eng) LJMD_CHILD(h, e, ljmd_set_accel(e, m->stage[9].data(), m->stage[10].data(), m->stage[11].data()));
     h->have_accel = true;
     return LJMD_OK;
 }
 
 int set_unwrapped(ljmd_t *h, const double *ux, const double *uy, const double *uz)
 {
-    for (ljmd_t *e : h->multi->eng) LJMD_CHILD(h, e, ljmd_set_unwrapped(e, ux, uy, uz));
+    ljmd_multi *m = h->multi;
+    const double *in[3] = {ux, uy, uz};
+    to_engine_order(m, h->n, in, 3);
+    for (ljmd_t *e : m->eng) LJMD_CHILD(h, e, ljmd_set_unwrapped(e, m->stage[3].data(), m->stage[4].data(), m->stage[5].data()));
     return LJMD_OK;
 }
 
+namespace {
+// the children's arrays (engine order, rank blocks) through `fetch`, then out[owner[k]] = engine[k]
+template <typename Fetch>
+int gather_by_owner(ljmd_t *h, double *const p[12], Fetch &&fetch)
+{
+    ljmd_multi *m = h->multi;
+    for (int k = 0; k < 12; ++k)
+        if (p[k]) m->stage[k].resize(h->n);
+    for (ljmd_t *e : m->eng) {
+        double *q[12];
+        for (int k = 0; k < 12; ++k) q[k] = p[k] ? m->stage[k].data() + (size_t)e->rank * e->S : nullptr;
+        LJMD_CHILD(h, e, fetch(e, q));
+    }
+    for (int k = 0; k < 12; ++k)
+        if (p[k])
+            for (int i = 0; i < h->n; ++i) p[k][m->owner[i]] = m->stage[k][i];
+    return LJMD_OK;
+}
+}  // namespace
+
 int get_state(ljmd_t *h, double *const p[12])
 {
-    for (ljmd_t *e : h->multi->eng) {
-        double *q[12];
-        for (int k = 0; k < 12; ++k) q[k] = p[k] ? p[k] + (size_t)e->rank * e->S : nullptr;
-        LJMD_CHILD(h, e, ljmd_get_state(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]));
-    }
-    return LJMD_OK;
+    return gather_by_owner(h, p, [](ljmd_t *e, double *const q[12]) {
+        return ljmd_get_state(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]);
+    });
 }
 
 int set_observables(ljmd_t *h, bool on)
@@ -340,8 +390,64 @@ int compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot)
     return collect(h, 1, epot, nullptr, d_epot, dd_epot);
 }
 
+namespace {
+// Deal the particles out again by position: engine order = sorted along the longest axis of the box-wide distribution
+// (rank g = the g-th n / G of them: a slab), every rank then k-d sorts its slab as after any set_state.  Through the
+// host: r, ru, v, a come down in engine order, are permuted, and go back up through the children's set_* calls.
+int migrate(ljmd_t *h)
+{
+    ljmd_multi *m = h->multi;
+    const int n = h->n;
+    double *p[12];
+    for (int k = 0; k < 12; ++k) {
+        m->stage[k].resize(n);
+        p[k] = m->stage[k].data();
+    }
+    for (ljmd_t *e : m->eng) {                                   // engine order, no owner mapping
+        double *q[12];
+        for (int k = 0; k < 12; ++k) q[k] = p[k] + (size_t)e->rank * e->S;
+        LJMD_CHILD(h, e, ljmd_get_state(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]));
+    }
+    int axis = 0;                                                // slabs along x (a cubic box: any axis serves)
+    std::vector<int32_t> order(n);
+    for (int k = 0; k < n; ++k) order[k] = k;
+    const double *key = p[axis];
+    std::stable_sort(order.begin(), order.end(), [key](int32_t a_, int32_t b_) { return key[a_] < key[b_]; });
+    std::vector<double> tmp(n);
+    for (int k = 0; k < 12; ++k) {
+        for (int i = 0; i < n; ++i) tmp[i] = p[k][order[i]];
+        m->stage[k].swap(tmp);
+        tmp.resize(n);
+        p[k] = m->stage[k].data();
+    }
+    std::vector<int32_t> owner(n);
+    for (int i = 0; i < n; ++i) owner[i] = m->owner[order[i]];
+    m->owner.swap(owner);
+    for (ljmd_t *e : m->eng) {
+        LJMD_CHILD(h, e, ljmd_set_state(e, p[0], p[1], p[2], p[6], p[7], p[8]));
+        LJMD_CHILD(h, e, ljmd_set_unwrapped(e, p[3], p[4], p[5]));
+        LJMD_CHILD(h, e, ljmd_set_accel(e, p[9], p[10], p[11]));
+    }
+    m->steps_since_migration = 0;
+    ++m->migrations;
+    return exchange_positions(h);
+}
+}  // namespace
+
+int32_t migrations(const ljmd_t *h) { return h->multi->migrations; }
+
 int enqueue_steps(ljmd_t *h, int32_t nsteps, bool sampled)
 {
+    {
+        ljmd_multi *m = h->multi;
+        bool snap = false;
+        for (const ljmd_t *e : m->eng) snap = snap || e->snap_in_flight;
+        // only at a quiet point: no step records waiting to be collected (ljmd_set_state restarts the children's rings),
+        // no snapshot on its way out (it is delivered through the owner table of its own moment)
+        if (m->migrate_every > 0 && m->steps_since_migration >= m->migrate_every && pending(h) == 0 && !snap && h->have_accel)
+            LJMD_TRY(migrate(h));
+        m->steps_since_migration += nsteps;
+    }
     if (pending(h) + (unsigned)nsteps > kRingCap)
         return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: %u + %d pending steps exceed LJMD_MAX_PENDING_STEPS", pending(h),
                     nsteps);
@@ -372,12 +478,10 @@ int snapshot_begin(ljmd_t *h)
 
 int snapshot_end(ljmd_t *h, double *const p[12])
 {
-    for (ljmd_t *e : h->multi->eng) {
-        double *q[12];
-        for (int k = 0; k < 12; ++k) q[k] = p[k] ? p[k] + (size_t)e->rank * e->S : nullptr;
-        LJMD_CHILD(h, e, ljmd_snapshot_end(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]));
-    }
-    return LJMD_OK;
+    // (no migration happens while a snapshot is in flight, so `owner` is still the one of snapshot_begin)
+    return gather_by_owner(h, p, [](ljmd_t *e, double *const q[12]) {
+        return ljmd_snapshot_end(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]);
+    });
 }
 
 int kinetic_energy(ljmd_t *h, double *ekin)

@@ -190,6 +190,10 @@ class Engine:
         fn = self._lib.ljmd_enqueue_steps_sampled if sampled else self._lib.ljmd_enqueue_steps
         self._ck(fn(self._h, nsteps))
 
+    def migrations(self) -> int:
+        """multi-device handle: ownership migrations so far (LJMD_MULTI_MIGRATE_EVERY)"""
+        return int(self._lib.ljmd_multi_migrations(self._h))
+
     def set_observables(self, on: bool) -> None:
         """phase API (sharded engines): forces-only force evaluations while off"""
         self._ck(self._lib.ljmd_set_observables(self._h, 1 if on else 0))

@@ -254,6 +254,62 @@ def test_multi_device_handle_emulated_ranks(n, G, monkeypatch):
         assert np.array_equal(np.stack(runs[1][2][key]), np.stack(st[key])), key
 
 
+@pytest.mark.parametrize("n,G", [(16384, 4), (8192, 8)])
+def test_multi_device_handle_ownership_migration(n, G, monkeypatch):
+    """A rank owns an index range, i.e. a fixed set of particles that diffuses out of its slab in a liquid; every
+    LJMD_MULTI_MIGRATE_EVERY steps the multi-device handle deals the particles out again by position.
+    With a migration before every 20-step segment: the energy series and the final state -- in the CALLER's particle order,
+    unwrapped positions included -- against the same run without migration and against the single engine; snapshots and
+    set_unwrapped / set_accel round trips through the owner table; run-to-run bitwise."""
+    monkeypatch.setenv("LJMD_N3_MIN_N", "1")
+    p, r, v = synthetic.make_config(n, seed=9)
+    segs, seg = 6, 20
+
+    def run(migrate_every, devices):
+        monkeypatch.setenv("LJMD_MULTI_MIGRATE_EVERY", str(migrate_every))
+        kw = dict(devices=devices) if devices else {}
+        with Engine(p, **kw) as eng:
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            eng.compute_forces()
+            rows, snap = [], None
+            for k in range(segs):
+                eng.enqueue_steps(seg)
+                if k == 3:
+                    eng.snapshot_begin()
+                rows.append(np.stack(eng.collect_steps(seg), axis=1))
+                if k == 3:
+                    snap = eng.snapshot_end()
+            st = eng.get_state()
+            n_mig = eng.migrations()
+            # round trip through the owner table: what get_state returned goes back in and comes out unchanged
+            eng.set_unwrapped(*st["ru"])
+            eng.set_accel(*st["a"])
+            st2 = eng.get_state()
+            for key in ("r", "ru", "v", "a"):
+                assert np.array_equal(np.stack(st2[key]), np.stack(st[key])), key
+            more = np.stack(eng.verlet_steps(5), axis=1)
+        return np.concatenate(rows), st, snap, n_mig, more
+
+    sc_m, st_m, snap_m, n_mig, more_m = run(seg, [0] * G)
+    assert n_mig == segs - 1                                   # before every segment but the first
+    sc_0, st_0, snap_0, n0, more_0 = run(0, [0] * G)
+    assert n0 == 0
+    sc_1, st_1, snap_1, _n1, more_1 = run(0, None)             # the single engine
+    for sc in (sc_0, sc_1):
+        assert np.max(np.abs(sc_m - sc) / np.abs(sc)) < 1e-9
+    assert np.max(np.abs(more_m - more_1) / np.abs(more_1)) < 1e-9
+    for ref in (st_0, st_1):
+        for key in ("r", "ru", "v", "a"):
+            mine, want = np.stack(st_m[key]), np.stack(ref[key])
+            assert np.abs(mine - want).max() < 1e-7 * max(np.abs(want).max(), 1.0), key     # identities intact
+    for key in ("r", "ru", "v", "a"):
+        assert np.abs(np.stack(snap_m[key]) - np.stack(snap_1[key])).max() < 1e-7 * max(np.abs(np.stack(snap_1[key])).max(), 1.0), key
+    sc_again, st_again, _s, _n, _m = run(seg, [0] * G)
+    assert np.array_equal(sc_again, sc_m)
+    for key in ("r", "ru", "v", "a"):
+        assert np.array_equal(np.stack(st_again[key]), np.stack(st_m[key])), key
+
+
 def test_multi_device_handle_one_rank_equals_plain_engine_bitwise(monkeypatch):
     """n_gpus = 1: RCCL communicator over one device (ncclCommInitAll), no exchange needed -- bit for bit the plain
     engine, including the asynchronous production-loop entry points the Fortran driver uses."""

@@ -62,6 +62,7 @@ c0 = fake.fakehip_collectives()
 for n, devices, env in ((16384, [0, 1], {}), (16384, [0, 1, 2, 3], {}), (32768, list(range(8)), {}),
                         (3000, [0, 1, 2], {"LJMD_N3_MIN_N": "1"}), (4096, [2, 5], {"LJMD_N3": "0"}),
                         (16384, [0, 1, 2, 3], {"LJMD_MULTI_EXCHANGE": "copy"}), (16384, [0, 0, 0, 0], {}),
+                        (16384, [0, 1, 2, 3], {"LJMD_MULTI_MIGRATE_EVERY": "5"}),     # ownership migration between the segments
                         (24576, [0, 1, 2], {"LJMD_N3_ROW_TILES": "4", "LJMD_N3_WG_WAVES": "2", "LJMD_N3_MIN_N": "1"})):
     os.environ.update(env)
     p, r, v = synthetic.make_config(n, seed=5)
