@@ -309,13 +309,21 @@ int set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz, c
               const double *vz)
 {
     ljmd_multi *m = h->multi;
-    for (int k = 0; k < h->n; ++k) m->owner[k] = k;         // a new state starts from the caller's index ranges
+    for (int k = 0; k < h->n; ++k) m->owner[k] = k;
+    // the first deal is by position too (the caller's order may have nothing to do with space); with migration switched
+    // off, or one rank, the ranks own the caller's index ranges
+    if (m->G > 1 && m->migrate_every > 0)
+        std::stable_sort(m->owner.begin(), m->owner.end(), [rx](int32_t a_, int32_t b_) { return rx[a_] < rx[b_]; });
     m->steps_since_migration = 0;
+    const double *rin[3] = {rx, ry, rz}, *vin[3] = {vx, vy, vz};
+    to_engine_order(m, h->n, rin, 0);
+    to_engine_order(m, h->n, vin, 6);
     for (ljmd_t *e : m->eng) {
         // after a batch that failed half-way the ranks are a phase apart: every rank drains its stream and
         // re-synchronises its record ring with its own device count (ljmd_set_state on a poisoned engine)
         if (h->poisoned) e->poisoned = true;
-        LJMD_CHILD(h, e, ljmd_set_state(e, rx, ry, rz, vx, vy, vz));
+        LJMD_CHILD(h, e, ljmd_set_state(e, m->stage[0].data(), m->stage[1].data(), m->stage[2].data(), m->stage[6].data(),
+                                        m->stage[7].data(), m->stage[8].data()));
     }
     h->have_state = true;
     h->have_accel = false;
