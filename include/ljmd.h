@@ -247,9 +247,33 @@ int ljmd_allgather_positions(ljmd_t *h);
 /* Ranks RCCL itself reports for this handle's communicator (ncclCommCount); 0 = no communicator.
  * bench.py prints it so that a multi-GPU line proves the collective ran over all ranks. */
 int32_t ljmd_comm_size(const ljmd_t *h);
-/* multi-device handle: ownership migrations done so far (LJMD_MULTI_MIGRATE_EVERY, default every 2000 steps: the particles
- * are dealt out to the ranks again by position, because an index-range shard diffuses out of its slab in a liquid; the
- * caller's arrays keep their order); 0 for any other handle */
+/*
+ * Ownership migration of a multi-GPU run, on the devices.  A rank owns a fixed SET of particles, which in a liquid
+ * diffuses out of the region it filled when it was dealt (about 4 sigma rms in 10 000 steps): the rank's 64-particle
+ * tiles grow and the tile-pair test skips less (-9 % step rate over 10 000 steps at n = 65536 on 8 ranks).  A migration
+ * deals all n particles out again BY POSITION: every rank packs ru, v, a and the particle ids of its slots, one all-gather
+ * (80 n bytes over xGMI; the positions are in the exchange buffer already) brings everybody's to every rank, every rank
+ * computes the same k-d split of the n particles into G near-cubic blocks of exactly n / G (stable radix sorts on
+ * identical input: identical result everywhere), keeps block `rank`, re-sorts it into tiles and joins the next position
+ * all-gather.  Between two MD steps only (no step half enqueued); pending step records and a snapshot in flight are
+ * not affected.  No arithmetic of the path changes: the trajectory differs only by summation order.
+ *   ljmd_migrate           everything, collectives included: a multi-device handle (ljmd_create_multi; also done
+ *                          automatically every LJMD_MULTI_MIGRATE_EVERY steps, default 2000, and at ljmd_set_state), or a
+ *                          rank engine with an RCCL communicator (every rank calls it at the same step); no-op for 1 rank
+ *   ljmd_migrate_pack / _buffer / _deal   the phases around a caller-made exchange of the G blocks of the migration
+ *                          buffer (block g: 10 P doubles at offset g * 10 P; host-staged fallback, tests); the caller then
+ *                          also repeats the position exchange
+ *   ljmd_particle_ids      ids[j], j < n / n_ranks: index, in the arrays given to the last ljmd_set_state, of the particle at
+ *                          position j of this rank engine's arrays (ljmd_get_state, ljmd_snapshot_end); rank S + j until a
+ *                          migration.  ljmd_set_accel / ljmd_set_unwrapped keep taking the GLOBAL arrays in that order.
+ *                          (A multi-device handle keeps the caller's order itself: identity.)
+ *   ljmd_multi_migrations  migrations done so far on this handle
+ */
+int ljmd_migrate(ljmd_t *h);
+int ljmd_migrate_pack(ljmd_t *h);
+void *ljmd_migrate_buffer(ljmd_t *h, int64_t *n_doubles_total, int64_t *own_offset_doubles, int64_t *own_count_doubles);
+int ljmd_migrate_deal(ljmd_t *h);
+int ljmd_particle_ids(ljmd_t *h, int32_t *ids);
 int32_t ljmd_multi_migrations(const ljmd_t *h);
 /* Copy on the handle's stream, then wait: kind 1 = host->device, 2 = device->host, 3 = device->device.
  * For callers that stage the exchange / force buffers themselves (host-staged fallback, tests). */
@@ -309,6 +333,13 @@ int ljmd_profile_read(ljmd_t *h, double *ms_avg /* [4] */, int32_t *launches);
 /* Same, plus the minimum over the launches of each interval (ms_min[2] = the drift/kick kernel alone:
  * the steps that also re-sort are longer).  Either array may be NULL. */
 int ljmd_profile_read_ex(ljmd_t *h, double *ms_avg /* [4] */, double *ms_min /* [4] */, int32_t *launches);
+/* Per rank, with the two exchanges of a multi-GPU step: intervals 0..3 as above, ms[4] = the position
+ * all-gather, ms[5] = the force reduce-scatter / all-to-all (HIP events on the stream that carries the collective,
+ * from the moment this rank could start it: the wait for the slowest rank is part of it; 0 when the launches had no
+ * exchange).  `rank` selects the rank engine of a multi-device handle (ljmd_create_multi); on an ordinary engine it
+ * must be the engine's own rank.  Resets that rank's counters. */
+int ljmd_profile_read_rank(ljmd_t *h, int32_t rank, double *ms_avg /* [6] */, double *ms_min /* [6] */,
+                           int32_t *launches);
 
 #ifdef __cplusplus
 }

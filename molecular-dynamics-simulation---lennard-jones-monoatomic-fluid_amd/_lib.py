@@ -57,6 +57,11 @@ PROTOTYPES = {
     "ljmd_compute_forces": (C.c_int, [C.c_void_p] + [c_double_p] * 3),
     "ljmd_verlet_steps": (C.c_int, [C.c_void_p, C.c_int32] + [c_double_p] * 4),
     "ljmd_multi_migrations": (C.c_int32, [C.c_void_p]),
+    "ljmd_migrate": (C.c_int, [C.c_void_p]),
+    "ljmd_migrate_pack": (C.c_int, [C.c_void_p]),
+    "ljmd_migrate_buffer": (C.c_void_p, [C.c_void_p, c_int64_p, c_int64_p, c_int64_p]),
+    "ljmd_migrate_deal": (C.c_int, [C.c_void_p]),
+    "ljmd_particle_ids": (C.c_int, [C.c_void_p, c_int32_p]),
     "ljmd_enqueue_steps": (C.c_int, [C.c_void_p, C.c_int32]),
     "ljmd_enqueue_steps_sampled": (C.c_int, [C.c_void_p, C.c_int32]),
     "ljmd_set_observables": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -92,6 +97,7 @@ PROTOTYPES = {
     "ljmd_pair_kernel_name": (C.c_char_p, [C.c_void_p]),
     "ljmd_profile_read": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
     "ljmd_profile_read_ex": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p]),
+    "ljmd_profile_read_rank": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, c_int32_p]),
 }
 
 _lib = None

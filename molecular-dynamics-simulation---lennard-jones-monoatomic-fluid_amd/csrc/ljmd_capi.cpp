@@ -171,7 +171,9 @@ EventSet *next_events(ljmd_t *h)
             if (hipEventCreate(&e) != hipSuccess) return nullptr;
         h->ev_pool.push_back(q);
     }
-    return &h->ev_pool[h->ev_used++];
+    EventSet *q = &h->ev_pool[h->ev_used++];
+    q->has_pos_x = q->has_force_x = false;
+    return q;
 }
 
 // Spatial re-ordering of the owned shard: keys -> stable radix sort -> gather r, ru, v (+ a when
@@ -342,6 +344,7 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
         }
         const hipStream_t xs = cs ? h->comm_stream : h->stream;
         const size_t blk = 3 * (size_t)h->P;
+        if (q) LJMD_HIP(h, hipEventRecord(q->e[7], xs));
         if (h->exchange_alltoall) {
             // every rank sends block g of its fpart straight to rank g (one xGMI link per peer on the fully
             // connected mesh) and adds the G blocks it receives in rank order: explicit, reproducible sum order
@@ -357,6 +360,10 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
         } else {
             const ncclResult_t r = ncclReduceScatter(h->d_fpart, h->d_frecv, blk, ncclDouble, ncclSum, h->comm, xs);
             if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclReduceScatter failed: %s", ncclGetErrorString(r));
+        }
+        if (q) {
+            LJMD_HIP(h, hipEventRecord(q->e[8], xs));
+            q->has_force_x = true;
         }
         if (cs) {
             const int rc_ = comm_end(h);
@@ -384,37 +391,74 @@ int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
     return rc_ != LJMD_OK ? rc_ : enqueue_kick(h, kick, q);
 }
 
-int enqueue_drift(ljmd_t *h, EventSet *q)
+// K1, positions: drift + wrap + unwrapped update.  On a re-sort step (and only then) the whole of K1 runs here, followed
+// by the re-sort: the velocity half-kick must precede the permutation, so there is nothing left to overlap (*split = false).
+int enqueue_drift_positions(ljmd_t *h, EventSet *q, bool *split)
 {
     if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
     h->gather_done_for_step = false;
     const bool resort_now = h->sort_enabled && fast_path_ok(h) && h->steps_since_sort + 1 >= h->resort_every;
+    *split = !resort_now;
+    LJMD_HIP(h, launch_drift_kick(integrate_args(h), resort_now ? 0 : 1, h->stream));
+    h->positions_compact = true;  // freshly wrapped into [0, L]
+    if (h->sort_enabled && fast_path_ok(h) && ++h->steps_since_sort >= h->resort_every) {
+        if (*split) {             // (positions that only became compact with this wrap: finish K1 before permuting)
+            LJMD_HIP(h, launch_drift_kick(integrate_args(h), 2, h->stream));
+            *split = false;
+        }
+        return resort(h, false);  // a(t) is dead after the drift/kick: K3 rewrites it
+    }
+    return LJMD_OK;
+}
+
+// K1, velocities: the first half-kick (reads a(t), which nothing rewrites before the kick kernel of this step)
+int enqueue_drift_velocities(ljmd_t *h)
+{
+    LJMD_HIP(h, launch_drift_kick(integrate_args(h), 2, h->stream));
+    return LJMD_OK;
+}
+
+int enqueue_drift(ljmd_t *h, EventSet *q)
+{
     const bool collectives = h->comm && (h->G > 1 || h->force_collectives);
-    if (collectives && use_comm_stream(h) && !resort_now) {
+    if (collectives && use_comm_stream(h)) {
         // positions first; the all-gather starts on the communication stream as soon as they are final and
         // overlaps the velocity half-kick; the engine's stream resumes (geometry pre-pass, pair kernel) when
-        // the gathered positions have arrived.  (Re-sort steps permute the block after K1: serial path below.)
-        LJMD_HIP(h, launch_drift_kick(integrate_args(h), 1, h->stream));
-        int rc_ = comm_begin(h);
-        if (rc_ == LJMD_OK) rc_ = allgather_on(h, h->comm_stream);
+        // the gathered positions have arrived.  (Re-sort steps permute the block after K1: the gather then follows
+        // serially, ljmd_allgather_positions.)
+        bool split = false;
+        int rc_ = enqueue_drift_positions(h, q, &split);
+        if (rc_ != LJMD_OK || !split) return rc_;
+        rc_ = comm_begin(h);
         if (rc_ != LJMD_OK) return rc_;
+        if (q) LJMD_HIP(h, hipEventRecord(q->e[5], h->comm_stream));
+        rc_ = allgather_on(h, h->comm_stream);
+        if (rc_ != LJMD_OK) return rc_;
+        if (q) {
+            LJMD_HIP(h, hipEventRecord(q->e[6], h->comm_stream));
+            q->has_pos_x = true;
+        }
         LJMD_HIP(h, hipEventRecord(h->ev_gather_done, h->comm_stream));
-        LJMD_HIP(h, launch_drift_kick(integrate_args(h), 2, h->stream));     // runs while the gather is in flight
+        rc_ = enqueue_drift_velocities(h);                                   // runs while the gather is in flight
+        if (rc_ != LJMD_OK) return rc_;
         LJMD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gather_done, 0));
         h->gather_done_for_step = true;
-    } else {
-        IntegrateArgs ia = integrate_args(h);
-        // single rank, no re-sort behind this kernel: the drift kernel's waves are the tiles -- let them write
-        // the bounding boxes of the new positions and skip tile_boxes_kernel in the force evaluation that follows
-        // (only where a launch matters: at n = 262144 the six wave reductions cost the HBM-bound kernel more -- 8.0 ->
-        // 11.5 us -- than the 5 us boxes kernel they replace)
-        h->boxes_valid = h->fuse_small && h->G == 1 && h->n <= 65536 && !resort_now && fast_path_ok(h);
-        if (h->boxes_valid) {
-            ia.bbox = h->d_bbox;
-            ia.pos_tc = h->use_n3 ? h->d_pos_tc : nullptr;
-        }
-        LJMD_HIP(h, launch_drift_kick(ia, 0, h->stream));
+        return LJMD_OK;
     }
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
+    h->gather_done_for_step = false;
+    const bool resort_now = h->sort_enabled && fast_path_ok(h) && h->steps_since_sort + 1 >= h->resort_every;
+    IntegrateArgs ia = integrate_args(h);
+    // single rank, no re-sort behind this kernel: the drift kernel's waves are the tiles -- let them write
+    // the bounding boxes of the new positions and skip tile_boxes_kernel in the force evaluation that follows
+    // (only where a launch matters: at n = 262144 the six wave reductions cost the HBM-bound kernel more -- 8.0 ->
+    // 11.5 us -- than the 5 us boxes kernel they replace)
+    h->boxes_valid = h->fuse_small && h->G == 1 && h->n <= 65536 && !resort_now && fast_path_ok(h);
+    if (h->boxes_valid) {
+        ia.bbox = h->d_bbox;
+        ia.pos_tc = h->use_n3 ? h->d_pos_tc : nullptr;
+    }
+    LJMD_HIP(h, launch_drift_kick(ia, 0, h->stream));
     h->positions_compact = true;  // freshly wrapped into [0, L]
     if (h->sort_enabled && fast_path_ok(h) && ++h->steps_since_sort >= h->resort_every)
         return resort(h, false);  // a(t) is dead after the drift/kick: K3 rewrites it
@@ -478,7 +522,8 @@ void release(ljmd_t *h)
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv, h->d_fall,
                    h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket,
-                   h->d_desc, h->d_desc_far, h->d_pos_tc};
+                   h->d_desc, h->d_desc_far, h->d_pos_tc, h->d_gid0, h->d_mig, h->d_mig_idx, h->d_mig_idx2, h->d_mig_keys,
+                   h->d_mig_keys2, h->d_mig_offsets, h->d_mig_cub};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -539,6 +584,16 @@ void stage_permuted(ljmd_t *h, const double *x, const double *y, const double *z
     const double *src[3] = {x + off, y + off, z + off};
     for (int ax = 0; ax < 3; ++ax) {
         double *dst = h->h_stage + (size_t)ax * h->P;
+        if (h->migrated) {
+            // after an ownership migration the shard is a SET of the caller's particles, not an index range: position o
+            // of the engine's order holds particle h_gid0[o] of the arrays given to ljmd_set_state
+            const double *glob = src[ax] - off;
+            for (int i = 0; i < h->P; ++i) {
+                const int o = h->h_perm[i];
+                dst[i] = (o < h->S) ? glob[h->h_gid0[o]] : pad;
+            }
+            continue;
+        }
         for (int i = 0; i < h->P; ++i) {
             const int o = h->h_perm[i];
             dst[i] = (o < h->S) ? src[ax][o] : pad;
@@ -554,6 +609,115 @@ int upload_shard3(ljmd_t *h, double *dst, const double *x, const double *y, cons
     LJMD_HIP(h, hipMemcpyAsync(dst, h->h_stage, 3 * (size_t)h->P * sizeof(double), hipMemcpyHostToDevice,
                                h->stream));
     LJMD_HIP(h, hipStreamSynchronize(h->stream));  // staging buffer is reused
+    return LJMD_OK;
+}
+
+// ---- ownership migration ---------------------------------------------------------------------------------------------
+namespace {
+int migrate_prepare(ljmd_t *h)
+{
+    if (h->d_mig) return LJMD_OK;
+    const size_t n = (size_t)h->n;
+    // levels of the deal: segments = runs of whole shards, halved (lower half = ceil) until every segment is one shard;
+    // the split axis of a level is the longest remaining extent of the box-wide blocks (ties: x, y, z)
+    std::vector<int> offsets, bounds = {0, h->G};
+    double ext[3] = {h->L, h->L, h->L};
+    while (true) {
+        bool any = false;
+        for (size_t j = 0; j + 1 < bounds.size(); ++j) any = any || (bounds[j + 1] - bounds[j] > 1);
+        if (!any) break;
+        h->mig_level_off.push_back(offsets.size());
+        h->mig_level_nseg.push_back((int)bounds.size() - 1);
+        for (int b : bounds) offsets.push_back(b * h->S);
+        int best = 0;
+        for (int ax = 1; ax < 3; ++ax)
+            if (ext[ax] > ext[best] * (1.0 + 1e-9)) best = ax;
+        h->mig_axis.push_back(best);
+        ext[best] *= 0.5;
+        std::vector<int> next;
+        for (size_t j = 0; j + 1 < bounds.size(); ++j) {
+            next.push_back(bounds[j]);
+            const int t = bounds[j + 1] - bounds[j];
+            if (t > 1) next.push_back(bounds[j] + (t + 1) / 2);
+        }
+        next.push_back(h->G);
+        bounds.swap(next);
+    }
+    for (int ax = 0; ax < 3; ++ax) h->mig_ext[ax] = ext[ax];
+    LJMD_HIP(h, hipMalloc(&h->d_mig_idx, n * sizeof(int)));
+    LJMD_HIP(h, hipMalloc(&h->d_mig_idx2, n * sizeof(int)));
+    LJMD_HIP(h, hipMalloc(&h->d_mig_keys, n * sizeof(unsigned long long)));
+    LJMD_HIP(h, hipMalloc(&h->d_mig_keys2, n * sizeof(unsigned long long)));
+    h->mig_cub_bytes = kd_temp_bytes(h->n);
+    LJMD_HIP(h, hipMalloc(&h->d_mig_cub, std::max<size_t>(h->mig_cub_bytes, 16)));
+    LJMD_HIP(h, hipMalloc(&h->d_mig_offsets, std::max<size_t>(offsets.size(), 2) * sizeof(int)));
+    if (!offsets.empty())
+        LJMD_HIP(h, hipMemcpyAsync(h->d_mig_offsets, offsets.data(), offsets.size() * sizeof(int), hipMemcpyHostToDevice,
+                                   h->stream));
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));      // `offsets` goes out of scope
+    LJMD_HIP(h, hipMalloc(&h->d_mig, (size_t)h->G * kMigrateRows * h->P * sizeof(double)));   // last: marks "prepared"
+    return LJMD_OK;
+}
+}  // namespace
+
+double *migrate_buffer(ljmd_t *h) { return h->d_mig; }
+
+int migrate_pack(ljmd_t *h)
+{
+    const int rc_ = migrate_prepare(h);
+    if (rc_ != LJMD_OK) return rc_;
+    LJMD_HIP(h, launch_migrate_pack(h->d_ru, h->d_v, h->d_a, h->d_perm, h->d_gid0,
+                                    h->d_mig + (size_t)h->rank * kMigrateRows * h->P, h->S, h->P, h->stream));
+    return LJMD_OK;
+}
+
+int migrate_deal(ljmd_t *h)
+{
+    if (!h->d_mig) return fail(h, LJMD_ERR_STATE, "migrate_deal: migrate_pack has not run");
+    LJMD_HIP(h, launch_iota_blocked(h->d_mig_idx, h->n, h->S, h->P, h->stream));
+    int *cur = h->d_mig_idx, *nxt = h->d_mig_idx2;
+    for (size_t l = 0; l < h->mig_level_nseg.size(); ++l) {
+        LJMD_HIP(h, kd_level_blocked(h->d_mig_cub, h->mig_cub_bytes, h->d_pos, h->mig_axis[l], h->P, h->L, h->d_mig_keys,
+                                     h->d_mig_keys2, cur, nxt, h->n, h->mig_level_nseg[l],
+                                     h->d_mig_offsets + h->mig_level_off[l], h->stream));
+        std::swap(cur, nxt);
+    }
+    LJMD_HIP(h, launch_migrate_select(h->d_pos, h->d_mig, cur + (size_t)h->rank * h->S, h->d_tmp3, h->d_ru, h->d_v, h->d_a,
+                                      h->d_gid0, h->S, h->P, h->stream));
+    LJMD_HIP(h, hipMemcpyAsync(own_block(h), h->d_tmp3, 3 * (size_t)h->P * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    // the new members in the order of the deal ARE the engine's original order now: identity permutation, then the
+    // shard's own k-d order (split axes from the block's extents, as ljmd_set_state chooses them)
+    LJMD_HIP(h, launch_iota(h->d_perm, h->P, h->stream));
+    for (int i = 0; i < h->P; ++i) h->h_perm[i] = i;
+    h->perm_dirty = false;
+    {
+        double ext[3] = {h->mig_ext[0], h->mig_ext[1], h->mig_ext[2]};
+        h->kd_axis.assign(h->kd_level_nseg.size(), 0);
+        for (size_t l = 0; l < h->kd_axis.size(); ++l) {
+            int best = 0;
+            for (int ax = 1; ax < 3; ++ax)
+                if (ext[ax] > ext[best] * (1.0 + 1e-9)) best = ax;
+            h->kd_axis[l] = best;
+            ext[best] *= 0.5;
+        }
+    }
+    h->boxes_valid = false;
+    h->h_gid0.resize(h->P);
+    LJMD_HIP(h, hipMemcpyAsync(h->h_gid0.data(), h->d_gid0, (size_t)h->P * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (h->sort_enabled && fast_path_ok(h)) {
+        const int rc_ = resort(h, true);               // a(t) is live between two steps
+        if (rc_ != LJMD_OK) return rc_;
+    }
+    LJMD_HIP(h, hipStreamSynchronize(h->stream));
+    h->migrated = true;
+    ++h->migrations;
+    return LJMD_OK;
+}
+
+int migrate_rebase(ljmd_t *h)
+{
+    LJMD_HIP(h, launch_iota_offset(h->d_gid0, h->S, h->P, h->rank * h->S, h->stream));
+    h->migrated = false;
     return LJMD_OK;
 }
 
@@ -722,7 +886,10 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->Q = (h->Dmax + wg) * rt;
         h->Q2 = (h->Dmax + 1) * rt;
         const int n3_min = env_int("LJMD_N3_MIN_N", 4096);
-        h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min;
+        // (rc within 1e-9 of L/2 -- the reference accepts rc_over_L up to 0.5 and rejects only rc >= L/2 -- takes the exact
+        //  generic kernel, which has no Newton-3 form: a multi-rank run then needs no force exchange at all, and every
+        //  rank must know that when it allocates)
+        h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min && (h->G == 1 || h->rc_allows_fast);
         const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 131072));
         int ns = (target_waves + h->NGo - 1) / h->NGo;
         const int n_off = h->Dmax + h->wg_waves;          // offsets a workgroup walks (relative to its first row group)
@@ -791,6 +958,8 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_idx2, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, hipMalloc(&h->d_perm, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, hipMalloc(&h->d_perm2, (size_t)h->P * sizeof(int)));
+        LJMD_HIP(h, hipMalloc(&h->d_gid0, (size_t)h->P * sizeof(int)));
+        LJMD_HIP(h, launch_iota_offset(h->d_gid0, h->S, h->P, h->rank * h->S, h->stream));
         h->cub_bytes = std::max(sort_temp_bytes(h->P), kd_temp_bytes(h->S));
         LJMD_HIP(h, hipMalloc(&h->d_cub, std::max<size_t>(h->cub_bytes, 16)));
         LJMD_HIP(h, hipMalloc(&h->d_kd_keys, (size_t)h->P * sizeof(unsigned long long)));
@@ -903,7 +1072,9 @@ int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *
     LJMD_HIP(h, hipMemcpyAsync(h->d_ru, own_block(h), 3 * P * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     LJMD_HIP(h, hipMemsetAsync(h->d_a, 0, 3 * P * sizeof(double), h->stream));
     LJMD_HIP(h, hipStreamSynchronize(h->stream));
-    // slot order is the original order again
+    // slot order is the original order again, and the shard is the caller's index range again
+    h->migrated = false;
+    LJMD_HIP(h, launch_iota_offset(h->d_gid0, h->S, h->P, h->rank * h->S, h->stream));
     for (int i = 0; i < h->P; ++i) h->h_perm[i] = i;
     LJMD_HIP(h, hipMemcpyAsync(h->d_perm, h->h_perm.data(), P * sizeof(int), hipMemcpyHostToDevice, h->stream));
     h->perm_dirty = false;
@@ -1343,9 +1514,77 @@ int ljmd_comm_init(ljmd_t *h, const char *id)
     return LJMD_OK;
 }
 
+// ---- ownership migration (multi-GPU) -------------------------------------------------------------------------------
+
+int ljmd_migrate_pack(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_migrate_pack: NULL handle");
+    if (h->multi) return fail(h, LJMD_ERR_STATE, "ljmd_migrate_pack: a multi-device handle migrates through ljmd_migrate");
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_migrate_pack: no state has been set");
+    if (h->forces_pending) return fail(h, LJMD_ERR_STATE, "ljmd_migrate_pack: a step is half enqueued");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    return migrate_pack(h);
+}
+
+void *ljmd_migrate_buffer(ljmd_t *h, int64_t *n_total, int64_t *own_off, int64_t *own_cnt)
+{
+    if (!h || h->multi) return nullptr;
+    const int64_t blk = (int64_t)kMigrateRows * h->P;
+    if (n_total) *n_total = blk * h->G;
+    if (own_off) *own_off = blk * h->rank;
+    if (own_cnt) *own_cnt = blk;
+    return migrate_buffer(h);
+}
+
+int ljmd_migrate_deal(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_migrate_deal: NULL handle");
+    if (h->multi) return fail(h, LJMD_ERR_STATE, "ljmd_migrate_deal: a multi-device handle migrates through ljmd_migrate");
+    LJMD_HIP(h, hipSetDevice(h->device));
+    return migrate_deal(h);
+}
+
+int ljmd_migrate(ljmd_t *h)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_migrate: NULL handle");
+    if (h->poisoned) return fail(h, LJMD_ERR_STATE, "ljmd_migrate: handle poisoned by an earlier failure; call ljmd_set_state");
+    if (h->multi) return ljmdm::migrate_now(h);
+    if (h->G == 1) return LJMD_OK;                       // one rank owns everything
+    if (!h->comm) return fail(h, LJMD_ERR_STATE, "ljmd_migrate: no communicator (use ljmd_migrate_pack / _deal around your own exchange)");
+    int rc_ = ljmd_migrate_pack(h);
+    if (rc_ != LJMD_OK) return rc_;
+    // all collectives of the communicator on ONE stream (see comm_begin): the blocks of everybody's ru, v, a and ids
+    const bool cs = use_comm_stream(h);
+    const hipStream_t xs = cs ? h->comm_stream : h->stream;
+    if (cs && (rc_ = comm_begin(h)) != LJMD_OK) return rc_;
+    const size_t blk = (size_t)kMigrateRows * h->P;
+    const ncclResult_t r = ncclAllGather(h->d_mig + (size_t)h->rank * blk, h->d_mig, blk, ncclDouble, h->comm, xs);
+    if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "ncclAllGather (migration) failed: %s", ncclGetErrorString(r));
+    if (cs && (rc_ = comm_end(h)) != LJMD_OK) return rc_;
+    if ((rc_ = migrate_deal(h)) != LJMD_OK) return rc_;
+    h->gather_done_for_step = false;
+    return ljmd_allgather_positions(h);                  // every rank's block changed
+}
+
+int ljmd_particle_ids(ljmd_t *h, int32_t *ids)
+{
+    if (!h || !ids) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_particle_ids: NULL argument");
+    if (h->multi) {                                      // global arrays in the caller's order, whatever migrated inside
+        for (int32_t k = 0; k < h->n; ++k) ids[k] = k;
+        return LJMD_OK;
+    }
+    if (!h->migrated) {
+        for (int32_t j = 0; j < h->S; ++j) ids[j] = h->rank * h->S + j;
+        return LJMD_OK;
+    }
+    static_assert(sizeof(int32_t) == sizeof(int), "particle ids are int32");
+    std::memcpy(ids, h->h_gid0.data(), (size_t)h->S * sizeof(int32_t));
+    return LJMD_OK;
+}
+
 int32_t ljmd_multi_migrations(const ljmd_t *h)
 {
-    return (h && h->multi) ? ljmdm::migrations(h) : 0;
+    return !h ? 0 : h->multi ? ljmdm::migrations(h) : h->migrations;
 }
 
 int32_t ljmd_comm_size(const ljmd_t *h)
@@ -1370,11 +1609,19 @@ int ljmd_allgather_positions(ljmd_t *h)
     }
     // serial form (t = 0, re-sort steps, LJMD_OVERLAP_EXCHANGE=0): behind the drift/kick (and re-sort) kernels
     // and ahead of the pair kernel
-    if (!use_comm_stream(h)) return allgather_on(h, h->stream);
-    int rc_ = comm_begin(h);
-    if (rc_ == LJMD_OK) rc_ = allgather_on(h, h->comm_stream);
-    if (rc_ == LJMD_OK) rc_ = comm_end(h);
-    return rc_;
+    EventSet *q = (h->profiling && h->ev_used > 0) ? &h->ev_pool[h->ev_used - 1] : nullptr;
+    const bool cs = use_comm_stream(h);
+    const hipStream_t xs = cs ? h->comm_stream : h->stream;
+    int rc_ = cs ? comm_begin(h) : LJMD_OK;
+    if (rc_ != LJMD_OK) return rc_;
+    if (q) LJMD_HIP(h, hipEventRecord(q->e[5], xs));
+    rc_ = allgather_on(h, xs);
+    if (rc_ != LJMD_OK) return rc_;
+    if (q) {
+        LJMD_HIP(h, hipEventRecord(q->e[6], xs));
+        q->has_pos_x = true;
+    }
+    return cs ? comm_end(h) : LJMD_OK;
 }
 
 int ljmd_memcpy(ljmd_t *h, void *dst, const void *src, int64_t bytes, int32_t kind)
@@ -1425,27 +1672,42 @@ int ljmd_profile_read(ljmd_t *h, double *ms_avg, int32_t *launches)
     return ljmd_profile_read_ex(h, ms_avg, nullptr, launches);
 }
 
-int ljmd_profile_read_ex(ljmd_t *h, double *ms_avg, double *ms_min, int32_t *launches)
+namespace {
+// intervals 0..3 as documented for ljmd_profile_read; 4 = position exchange, 5 = force exchange (averages over the
+// launches that had one; 0 when none did)
+int profile_read_full(ljmd_t *h, double *ms_avg /* [6] */, double *ms_min /* [6] */, int32_t *launches)
 {
-    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_read: NULL handle");
-    if (h->multi) return ljmdm::profile_read_ex(h, ms_avg, ms_min, launches);
     LJMD_HIP(h, hipSetDevice(h->device));
     LJMD_HIP(h, hipStreamSynchronize(h->stream));
-    double acc[4] = {0, 0, 0, 0};  // pair kernel, geometry pre-pass, drift/kick, reduce+finalize
-    double lo[4] = {1e300, 1e300, 1e300, 1e300};
-    const int from[4] = {2, 1, 0, 3}, to[4] = {3, 2, 1, 4};
+    if (h->comm_stream) LJMD_HIP(h, hipStreamSynchronize(h->comm_stream));
+    double acc[6] = {0, 0, 0, 0, 0, 0};  // pair kernel, geometry pre-pass, drift/kick, reduce+finalize, exchanges
+    double lo[6] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300};
+    size_t cnt_x[2] = {0, 0};
+    const int from[6] = {2, 1, 0, 3, 5, 7}, to[6] = {3, 2, 1, 4, 6, 8};
     size_t complete = 0;
     for (size_t k = 0; k < h->ev_used; ++k) {
-        double one[4];
+        const EventSet &q = h->ev_pool[k];
+        double one[6] = {0, 0, 0, 0, 0, 0};
         bool ok = true;
         for (int c = 0; c < 4 && ok; ++c) {
             float ms = 0.f;   // a set whose step was only half enqueued has unrecorded events: skip it
-            ok = hipEventElapsedTime(&ms, h->ev_pool[k].e[from[c]], h->ev_pool[k].e[to[c]]) == hipSuccess;
+            ok = hipEventElapsedTime(&ms, q.e[from[c]], q.e[to[c]]) == hipSuccess;
             one[c] = ms;
         }
         if (!ok) {
             (void)hipGetLastError();
             continue;
+        }
+        const bool have[2] = {q.has_pos_x, q.has_force_x};
+        for (int x = 0; x < 2; ++x) {
+            float ms = 0.f;
+            if (have[x] && hipEventElapsedTime(&ms, q.e[from[4 + x]], q.e[to[4 + x]]) == hipSuccess) {
+                acc[4 + x] += ms;
+                lo[4 + x] = std::min(lo[4 + x], (double)ms);
+                ++cnt_x[x];
+            } else if (have[x]) {
+                (void)hipGetLastError();
+            }
         }
         for (int c = 0; c < 4; ++c) {
             acc[c] += one[c];
@@ -1455,13 +1717,42 @@ int ljmd_profile_read_ex(ljmd_t *h, double *ms_avg, double *ms_min, int32_t *lau
     }
     h->ev_used = complete;
     const double cnt = h->ev_used ? (double)h->ev_used : 1.0;
-    if (ms_avg)
-        for (int c = 0; c < 4; ++c) ms_avg[c] = acc[c] / cnt;
-    if (ms_min)
-        for (int c = 0; c < 4; ++c) ms_min[c] = h->ev_used ? lo[c] : 0.0;
+    for (int c = 0; c < 6; ++c) {
+        const double div = c < 4 ? cnt : (cnt_x[c - 4] ? (double)cnt_x[c - 4] : 1.0);
+        const bool any = c < 4 ? h->ev_used > 0 : cnt_x[c - 4] > 0;
+        if (ms_avg) ms_avg[c] = acc[c] / div;
+        if (ms_min) ms_min[c] = any ? lo[c] : 0.0;
+    }
     if (launches) *launches = (int32_t)h->ev_used;
     h->ev_used = 0;
     return LJMD_OK;
+}
+}  // namespace
+
+int ljmd_profile_read_ex(ljmd_t *h, double *ms_avg, double *ms_min, int32_t *launches)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_read: NULL handle");
+    if (h->multi) return ljmdm::profile_read_ex(h, ms_avg, ms_min, launches);
+    double a[6], b[6];
+    const int rc_ = profile_read_full(h, a, b, launches);
+    if (rc_ != LJMD_OK) return rc_;
+    if (ms_avg) std::memcpy(ms_avg, a, 4 * sizeof(double));
+    if (ms_min) std::memcpy(ms_min, b, 4 * sizeof(double));
+    return LJMD_OK;
+}
+
+int ljmd_profile_read_rank(ljmd_t *h, int32_t rank, double *ms_avg, double *ms_min, int32_t *launches)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_read_rank: NULL handle");
+    if (h->multi) {
+        ljmd_t *e = ljmdm::rank_engine(h, rank);
+        if (!e) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_profile_read_rank: rank %d out of range", rank);
+        const int rc_ = profile_read_full(e, ms_avg, ms_min, launches);
+        if (rc_ != LJMD_OK) return fail(h, rc_, "rank %d (device %d): %s", e->rank, e->device, e->err.c_str());
+        return LJMD_OK;
+    }
+    if (rank != h->rank) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_profile_read_rank: this engine is rank %d", h->rank);
+    return profile_read_full(h, ms_avg, ms_min, launches);
 }
 
 // ---- stateless drop-ins ----------------------------------------------------------

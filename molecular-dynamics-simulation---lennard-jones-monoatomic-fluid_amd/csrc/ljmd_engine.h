@@ -32,13 +32,16 @@ constexpr int kMixedMinN = 16384;       // smallest system the mixed-precision m
 constexpr long kN3ItemsFor4 = 30000;    // Newton-3 work items (row groups x offsets) a rank needs before 4 ...
 constexpr long kN3ItemsFor2 = 6144;     // ... or 2 tiles per row group pay off
 constexpr int kMaxProfiledLaunches = 4096;
-constexpr int kEventsPerLaunch = 5;
+constexpr int kEventsPerLaunch = 9;
 
 // md_types.f90:22
 constexpr double kPi = 3.1415926535897932384626433832795;
 
 struct EventSet {
-    hipEvent_t e[kEventsPerLaunch];  // 0: before K1, 1: before geometry, 2: before pair, 3: after pair, 4: end
+    // 0: before K1, 1: before geometry, 2: before pair, 3: after pair, 4: end (engine stream);
+    // 5 / 6: around the position exchange, 7 / 8: around the force exchange, on the stream that carries them
+    hipEvent_t e[kEventsPerLaunch];
+    bool has_pos_x = false, has_force_x = false;   // events 5 / 6 and 7 / 8 were recorded for this launch
 };
 
 inline int env_int(const char *name, int dflt)
@@ -157,6 +160,23 @@ struct ljmd {
     bool snap_in_flight = false;
     bool snap_ready = false;      // all of the above exist
 
+    // Ownership migration (multi-GPU, ljmd_capi.cpp: migrate_pack / migrate_deal).  gid0[j] = particle id -- global index in
+    // the order of the last ljmd_set_state (or of the last rebase) -- of the particle at position j of this engine's arrays
+    // (its "original order": what get_state returns and the slot permutation refers to); identity (rank S + j) until a deal
+    int *d_gid0 = nullptr;            // [P]
+    std::vector<int> h_gid0;          // host mirror, valid while `migrated`
+    bool migrated = false;            // the shard is no longer the index range [rank S, (rank + 1) S) of the caller's arrays
+    double *d_mig = nullptr;          // [G][kMigrateRows][P] migration buffer (lazy)
+    int *d_mig_idx = nullptr, *d_mig_idx2 = nullptr;                    // [n] storage indices g P + s
+    unsigned long long *d_mig_keys = nullptr, *d_mig_keys2 = nullptr;   // [n]
+    int *d_mig_offsets = nullptr;
+    void *d_mig_cub = nullptr;
+    size_t mig_cub_bytes = 0;
+    std::vector<int> mig_level_nseg, mig_axis;
+    std::vector<size_t> mig_level_off;
+    double mig_ext[3] = {0, 0, 0};    // extents of a rank's block after the deal (choose the shard's k-d axes)
+    int32_t migrations = 0;
+
     bool profiling = false;
     std::vector<EventSet> ev_pool;
     size_t ev_used = 0;
@@ -182,6 +202,11 @@ inline bool needs_force_exchange(const ljmd_t *h) { return h->use_n3 && (h->G > 
 
 // one MD step = enqueue_drift | position exchange (multi-rank) | enqueue_pair_forces | force exchange | enqueue_kick
 int enqueue_drift(ljmd_t *h, EventSet *q);
+// the same in two halves, for a caller that issues the position exchange itself between them (ljmd_multi.cpp):
+// positions (+ re-sort on a re-sort step; *split = false then, and the velocity half-kick has already run) ...
+int enqueue_drift_positions(ljmd_t *h, EventSet *q, bool *split);
+// ... and the velocity half-kick, concurrent with the exchange
+int enqueue_drift_velocities(ljmd_t *h);
 int enqueue_pair_forces(ljmd_t *h, EventSet *q);
 int enqueue_kick(ljmd_t *h, bool kick, EventSet *q);
 int fetch_ring(ljmd_t *h, unsigned count);
@@ -189,6 +214,15 @@ void combine_one(const ljmd_t *h, const double *recs, int n_ranks, double *epot,
                  double *dd_epot);
 EventSet *next_events(ljmd_t *h);
 void release(ljmd_t *h);
+// ownership migration in three phases, all on the engine's stream: (1) the own block of the migration buffer <- ru, v, a,
+// ids; (2) -- by the caller or the library -- all-gather of the G blocks (kMigrateRows * P doubles each; block g at
+// migrate_buffer(h) + g * kMigrateRows * P); (3) the deal + the rank's new state (the exchange buffer must hold everybody's
+// CURRENT positions).  Afterwards the position exchange has to run again.
+int migrate_pack(ljmd_t *h);
+double *migrate_buffer(ljmd_t *h);
+int migrate_deal(ljmd_t *h);
+// a caller that keeps the composite table itself (ljmd_multi.cpp): the ids start again at rank S + j
+int migrate_rebase(ljmd_t *h);
 
 }  // namespace ljmdh
 #endif

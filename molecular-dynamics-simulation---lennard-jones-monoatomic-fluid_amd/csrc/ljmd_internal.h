@@ -168,6 +168,17 @@ hipError_t launch_iota(int *idx, int P, hipStream_t s);
 hipError_t kd_level(void *temp, size_t temp_bytes, const double *coord_axis, double L, unsigned long long *keys,
                     unsigned long long *keys_out, int *idx, int *idx_out, int S, int nseg, const int *seg_offsets,
                     hipStream_t s);
+// ownership migration of a multi-GPU run (ljmd_sort.hip; ljmd_capi.cpp: migrate_pack / migrate_deal)
+constexpr int kMigrateRows = 10;            // doubles per slot in the migration buffer: ru, v, a (3 each) + the particle id
+hipError_t launch_iota_blocked(int *idx, int n, int S, int P, hipStream_t s);
+hipError_t launch_iota_offset(int *idx, int count, int P, int offset, hipStream_t s);
+hipError_t kd_level_blocked(void *temp, size_t temp_bytes, const double *pos, int axis, int P, double L,
+                            unsigned long long *keys, unsigned long long *keys_out, int *idx, int *idx_out, int n, int nseg,
+                            const int *seg_offsets, hipStream_t s);
+hipError_t launch_migrate_pack(const double *ru, const double *v, const double *a, const int *perm, const int *gid0,
+                               double *block, int S, int P, hipStream_t s);
+hipError_t launch_migrate_select(const double *pos_all, const double *mig_all, const int *mine, double *new_pos, double *ru,
+                                 double *v, double *a, int *gid0, int S, int P, hipStream_t s);
 hipError_t launch_gather3(const double *src, double *dst, const int *idx, int P, hipStream_t s);
 hipError_t launch_gather_perm(const int *src, int *dst, const int *idx, int P, hipStream_t s);
 

@@ -6,12 +6,18 @@
 // stream-ordered, with no host synchronisation inside a batch of steps:
 //   positions   drift kernels of all ranks | all-gather of the 3P-double position blocks | pair kernels
 //   forces      (Newton-3) pair kernels + slab reductions | reduce-scatter of fpart[G][3][P] | kick kernels
-// exchange = RCCL (default for distinct devices): ncclCommInitAll communicators, each collective issued for all
-//   ranks inside one ncclGroupStart/End from this one thread, on the engines' own streams;
+// exchange = rccl (default for distinct devices): ncclCommInitAll communicators, each collective issued for all
+//   ranks inside one ncclGroupStart/End from this one thread;
 // exchange = copy (LJMD_MULTI_EXCHANGE=copy, and always when a device is listed twice -- RCCL refuses two ranks
 //   on one device, so this is also how several ranks are rehearsed on one card): every rank PULLS the blocks it
-//   needs with peer-to-peer hipMemcpyAsync on its own stream behind the owner's event and adds the G force
-//   blocks in rank order (launch_sum_blocks): explicit, run-to-run deterministic summation order.
+//   needs with peer-to-peer hipMemcpyAsync behind the owner's event and adds the G force blocks in rank order
+//   (launch_sum_blocks): explicit, run-to-run deterministic summation order;
+// exchange = host (LJMD_MULTI_EXCHANGE=host): the same pulls staged through pinned host memory (device -> host by the
+//   owner, host -> device by every reader) -- needs neither RCCL nor peer access: the last rung of bench.py's ladder.
+// Every exchange runs on a per-rank COMMUNICATION stream, fenced against the rank's engine stream by events, so that the
+// position exchange overlaps the velocity half-kick of K1 (verlet.f90:72-74 reads a(t) and v only; the positions are final
+// at :58-63) exactly as in the one-process-per-GPU form (ljmd_capi.cpp: enqueue_drift); LJMD_OVERLAP_EXCHANGE=0 puts
+// everything back on the engine streams.
 // The per-step scalar records stay on the devices; they are read back once per batch and combined on the host
 // in rank order (combine_one), exactly as the multi-process path does.
 #include "ljmd_multi.h"
@@ -19,19 +25,29 @@
 using namespace ljmdk;
 using namespace ljmdh;
 
+enum Exchange { kRccl, kCopy, kHost };
+
 struct ljmd_multi {
     int G = 0;
     std::vector<ljmd_t *> eng;
     std::vector<int> dev;
-    bool rccl = false;
+    Exchange xmode = kCopy;
+    bool overlap = true;                          // LJMD_OVERLAP_EXCHANGE: exchanges on xs[g] instead of the engine streams
     std::vector<ncclComm_t> comm;
-    std::vector<hipEvent_t> ev_pos, ev_force;     // copy exchange: "rank g's block is ready"
+    std::vector<hipStream_t> xs;                  // per rank: the stream that carries its exchanges
+    std::vector<hipStream_t> xs_owned;            // ... those of them this handle created
+    // per rank, all without timing: positions final (engine stream) / everything received (xs); partial forces ready
+    // (engine stream) / summed forces received (xs); host exchange: own block staged in pinned host memory (xs)
+    std::vector<hipEvent_t> ev_pos, ev_got, ev_force, ev_fgot, ev_hpos, ev_hforce;
+    std::vector<double *> h_xpos, h_xforce;       // host exchange: pinned staging, [3P] and [G][3P] doubles per rank
     std::vector<double> recs;                     // [G][kPartialStride] scratch of one step
     // Ownership migration.  The ranks own index ranges of the ENGINE order; `owner[k]` = the caller's index of the particle
     // at engine index k (identity until the first migration).  Every `migrate_every` steps the particles are dealt out again
     // by position -- rank g takes the g-th n / G of them along the longest axis -- because a fixed SET of particles diffuses
     // out of the slab it filled at t = 0 and the rank's 64-particle tiles grow (profiles/r02_shard_mixing_long_run.txt).
     std::vector<int32_t> owner;
+    std::vector<int32_t> owner_snap;              // the table as of ljmd_snapshot_begin: a snapshot in flight is delivered
+                                                  // through it, whatever migrations happen before ljmd_snapshot_end
     int migrate_every = 0, steps_since_migration = 0, migrations = 0;
     std::vector<double> stage[12];                // engine-order staging of r, ru, v, a (x, y, z each)
 };
@@ -67,68 +83,148 @@ void to_engine_order(ljmd_multi *m, int n, const double *const in[3], int base)
     }
 }
 
-int exchange_positions(ljmd_t *h)
+int nccl_failed(ljmd_t *h, const char *what, ncclResult_t r)
+{
+    return fail(h, LJMD_ERR_HIP, "multi-device %s failed: %s", what, ncclGetErrorString(r));
+}
+
+// Position exchange: every rank's own block (3P doubles, final for this step) into every other rank's exchange buffer.
+// Issued on the communication streams xs[g]; nothing on an engine stream waits for it until await_positions().
+// q: the ranks' event sets of this step (NULL entries: not profiled).
+int exchange_positions(ljmd_t *h, const std::vector<EventSet *> &q)
 {
     ljmd_multi *m = h->multi;
-    if (m->G == 1 && !m->eng[0]->force_collectives) return LJMD_OK;
-    if (m->rccl) {
+    const int G = m->G;
+    if (G == 1 && !m->eng[0]->force_collectives) return LJMD_OK;
+    for (int g = 0; g < G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_HIP(h, hipEventRecord(m->ev_pos[g], m->eng[g]->stream));
+        // the rank's own event first: behind it the rank's previous pair kernel has finished reading the blocks that are
+        // about to be overwritten, and the exchange interval (events 5 -> 6) starts when THIS rank could start
+        LJMD_HIP(h, hipStreamWaitEvent(m->xs[g], m->ev_pos[g], 0));
+        if (q[g]) LJMD_HIP(h, hipEventRecord(q[g]->e[5], m->xs[g]));
+    }
+    if (m->xmode == kRccl) {
         ncclResult_t r = ncclGroupStart();
-        for (int g = 0; g < m->G && r == ncclSuccess; ++g) {
+        for (int g = 0; g < G && r == ncclSuccess; ++g) {
             ljmd_t *e = m->eng[g];
-            r = ncclAllGather(own_block(e), e->d_pos, 3 * (size_t)e->P, ncclDouble, m->comm[g], e->stream);
+            r = ncclAllGather(own_block(e), e->d_pos, 3 * (size_t)e->P, ncclDouble, m->comm[g], m->xs[g]);
         }
         const ncclResult_t end = ncclGroupEnd();
         if (r == ncclSuccess) r = end;
-        if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "multi-device all-gather failed: %s", ncclGetErrorString(r));
-        return LJMD_OK;
-    }
-    for (int g = 0; g < m->G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        LJMD_HIP(h, hipEventRecord(m->ev_pos[g], m->eng[g]->stream));
-    }
-    for (int d = 0; d < m->G; ++d) {
-        ljmd_t *dst = m->eng[d];
-        LJMD_HIP(h, hipSetDevice(m->dev[d]));
-        const size_t blk = 3 * (size_t)dst->P;
-        for (int g = 0; g < m->G; ++g) {
-            if (g == d) continue;
-            LJMD_HIP(h, hipStreamWaitEvent(dst->stream, m->ev_pos[g], 0));
-            LJMD_HIP(h, hipMemcpyAsync(dst->d_pos + (size_t)g * blk, own_block(m->eng[g]), blk * sizeof(double),
-                                       hipMemcpyDeviceToDevice, dst->stream));
+        if (r != ncclSuccess) return nccl_failed(h, "all-gather", r);
+    } else {
+        if (m->xmode == kHost)
+            for (int g = 0; g < G; ++g) {
+                LJMD_HIP(h, hipSetDevice(m->dev[g]));
+                LJMD_HIP(h, hipMemcpyAsync(m->h_xpos[g], own_block(m->eng[g]), 3 * (size_t)m->eng[g]->P * sizeof(double),
+                                           hipMemcpyDeviceToHost, m->xs[g]));
+                LJMD_HIP(h, hipEventRecord(m->ev_hpos[g], m->xs[g]));
+            }
+        for (int d = 0; d < G; ++d) {
+            ljmd_t *dst = m->eng[d];
+            LJMD_HIP(h, hipSetDevice(m->dev[d]));
+            const size_t blk = 3 * (size_t)dst->P;
+            for (int g = 0; g < G; ++g) {
+                if (g == d) continue;
+                if (m->xmode == kHost) {
+                    LJMD_HIP(h, hipStreamWaitEvent(m->xs[d], m->ev_hpos[g], 0));
+                    LJMD_HIP(h, hipMemcpyAsync(dst->d_pos + (size_t)g * blk, m->h_xpos[g], blk * sizeof(double),
+                                               hipMemcpyHostToDevice, m->xs[d]));
+                } else {
+                    LJMD_HIP(h, hipStreamWaitEvent(m->xs[d], m->ev_pos[g], 0));
+                    LJMD_HIP(h, hipMemcpyAsync(dst->d_pos + (size_t)g * blk, own_block(m->eng[g]), blk * sizeof(double),
+                                               hipMemcpyDeviceToDevice, m->xs[d]));
+                }
+            }
         }
+    }
+    for (int g = 0; g < G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        if (q[g]) {
+            LJMD_HIP(h, hipEventRecord(q[g]->e[6], m->xs[g]));
+            q[g]->has_pos_x = true;
+        }
+        LJMD_HIP(h, hipEventRecord(m->ev_got[g], m->xs[g]));
     }
     return LJMD_OK;
 }
 
-int exchange_forces(ljmd_t *h)
+// the engine streams resume behind the position exchange
+int await_positions(ljmd_t *h)
 {
     ljmd_multi *m = h->multi;
+    if (m->G == 1 && !m->eng[0]->force_collectives) return LJMD_OK;
+    for (int g = 0; g < m->G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_HIP(h, hipStreamWaitEvent(m->eng[g]->stream, m->ev_got[g], 0));
+    }
+    return LJMD_OK;
+}
+
+int exchange_positions_now(ljmd_t *h)
+{
+    const std::vector<EventSet *> none(h->multi->G, nullptr);
+    LJMD_TRY(exchange_positions(h, none));
+    return await_positions(h);
+}
+
+// Force exchange (Newton-3): rank d's frecv = sum over the ranks g of block d of rank g's fpart, in rank order; the
+// engine streams wait for it (the kick kernel reads frecv).
+int exchange_forces(ljmd_t *h, const std::vector<EventSet *> &q)
+{
+    ljmd_multi *m = h->multi;
+    const int G = m->G;
     if (!needs_force_exchange(m->eng[0])) return LJMD_OK;     // gather kernels: every rank already has its rows
-    if (m->rccl) {
+    for (int g = 0; g < G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_HIP(h, hipEventRecord(m->ev_force[g], m->eng[g]->stream));
+        LJMD_HIP(h, hipStreamWaitEvent(m->xs[g], m->ev_force[g], 0));
+        if (q[g]) LJMD_HIP(h, hipEventRecord(q[g]->e[7], m->xs[g]));
+    }
+    if (m->xmode == kRccl) {
         ncclResult_t r = ncclGroupStart();
-        for (int g = 0; g < m->G && r == ncclSuccess; ++g) {
+        for (int g = 0; g < G && r == ncclSuccess; ++g) {
             ljmd_t *e = m->eng[g];
-            r = ncclReduceScatter(e->d_fpart, e->d_frecv, 3 * (size_t)e->P, ncclDouble, ncclSum, m->comm[g], e->stream);
+            r = ncclReduceScatter(e->d_fpart, e->d_frecv, 3 * (size_t)e->P, ncclDouble, ncclSum, m->comm[g], m->xs[g]);
         }
         const ncclResult_t end = ncclGroupEnd();
         if (r == ncclSuccess) r = end;
-        if (r != ncclSuccess) return fail(h, LJMD_ERR_HIP, "multi-device reduce-scatter failed: %s", ncclGetErrorString(r));
-        return LJMD_OK;
-    }
-    for (int g = 0; g < m->G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        LJMD_HIP(h, hipEventRecord(m->ev_force[g], m->eng[g]->stream));
-    }
-    for (int d = 0; d < m->G; ++d) {
-        ljmd_t *dst = m->eng[d];
-        LJMD_HIP(h, hipSetDevice(m->dev[d]));
-        const size_t blk = 3 * (size_t)dst->P;
-        for (int g = 0; g < m->G; ++g) {
-            if (g != d) LJMD_HIP(h, hipStreamWaitEvent(dst->stream, m->ev_force[g], 0));
-            LJMD_HIP(h, hipMemcpyAsync(dst->d_fall + (size_t)g * blk, m->eng[g]->d_fpart + (size_t)d * blk,
-                                       blk * sizeof(double), hipMemcpyDeviceToDevice, dst->stream));
+        if (r != ncclSuccess) return nccl_failed(h, "reduce-scatter", r);
+    } else {
+        if (m->xmode == kHost)
+            for (int g = 0; g < G; ++g) {
+                LJMD_HIP(h, hipSetDevice(m->dev[g]));
+                LJMD_HIP(h, hipMemcpyAsync(m->h_xforce[g], m->eng[g]->d_fpart, (size_t)G * 3 * m->eng[g]->P * sizeof(double),
+                                           hipMemcpyDeviceToHost, m->xs[g]));
+                LJMD_HIP(h, hipEventRecord(m->ev_hforce[g], m->xs[g]));
+            }
+        for (int d = 0; d < G; ++d) {
+            ljmd_t *dst = m->eng[d];
+            LJMD_HIP(h, hipSetDevice(m->dev[d]));
+            const size_t blk = 3 * (size_t)dst->P;
+            for (int g = 0; g < G; ++g) {
+                if (m->xmode == kHost) {
+                    LJMD_HIP(h, hipStreamWaitEvent(m->xs[d], m->ev_hforce[g], 0));
+                    LJMD_HIP(h, hipMemcpyAsync(dst->d_fall + (size_t)g * blk, m->h_xforce[g] + (size_t)d * blk,
+                                               blk * sizeof(double), hipMemcpyHostToDevice, m->xs[d]));
+                } else {
+                    if (g != d) LJMD_HIP(h, hipStreamWaitEvent(m->xs[d], m->ev_force[g], 0));
+                    LJMD_HIP(h, hipMemcpyAsync(dst->d_fall + (size_t)g * blk, m->eng[g]->d_fpart + (size_t)d * blk,
+                                               blk * sizeof(double), hipMemcpyDeviceToDevice, m->xs[d]));
+                }
+            }
+            LJMD_HIP(h, launch_sum_blocks(dst->d_fall, dst->d_frecv, G, (int)blk, m->xs[d]));   // rank order
         }
-        LJMD_HIP(h, launch_sum_blocks(dst->d_fall, dst->d_frecv, m->G, (int)blk, dst->stream));   // rank order
+    }
+    for (int g = 0; g < G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        if (q[g]) {
+            LJMD_HIP(h, hipEventRecord(q[g]->e[8], m->xs[g]));
+            q[g]->has_force_x = true;
+        }
+        LJMD_HIP(h, hipEventRecord(m->ev_fgot[g], m->xs[g]));
+        LJMD_HIP(h, hipStreamWaitEvent(m->eng[g]->stream, m->ev_fgot[g], 0));
     }
     return LJMD_OK;
 }
@@ -141,7 +237,7 @@ int enqueue_forces_all(ljmd_t *h, bool kick, const std::vector<EventSet *> &q)
         LJMD_HIP(h, hipSetDevice(m->dev[g]));
         LJMD_CHILD(h, m->eng[g], enqueue_pair_forces(m->eng[g], q[g]));
     }
-    LJMD_TRY(exchange_forces(h));
+    LJMD_TRY(exchange_forces(h, q));
     for (int g = 0; g < m->G; ++g) {
         LJMD_HIP(h, hipSetDevice(m->dev[g]));
         LJMD_CHILD(h, m->eng[g], enqueue_kick(m->eng[g], kick, q[g]));
@@ -152,13 +248,39 @@ int enqueue_forces_all(ljmd_t *h, bool kick, const std::vector<EventSet *> &q)
 int enqueue_one_step(ljmd_t *h)
 {
     ljmd_multi *m = h->multi;
-    std::vector<EventSet *> q(m->G, nullptr);
-    for (int g = 0; g < m->G; ++g) {
+    const int G = m->G;
+    std::vector<EventSet *> q(G, nullptr);
+    if (G > 1 && m->xmode != kRccl && !needs_force_exchange(m->eng[0])) {
+        // Without a force exchange (gather kernels: small systems, LJMD_N3=0) nothing orders a rank's next drift -- which
+        // overwrites its position block -- behind the OTHER ranks' pulls of that block in the previous step: with
+        // Newton-3 the kick waits for everybody's forces, which closes the hazard by itself.
+        for (int g = 0; g < G; ++g) {
+            LJMD_HIP(h, hipSetDevice(m->dev[g]));
+            for (int d = 0; d < G; ++d)
+                if (d != g) LJMD_HIP(h, hipStreamWaitEvent(m->eng[g]->stream, m->ev_got[d], 0));
+        }
+    }
+    // K1 in two halves: the positions (verlet.f90:58-63 + the unwrapped update) are final first, their exchange starts
+    // on the communication streams and the velocity half-kick (:72-74) runs beside it
+    bool split = m->overlap;
+    for (int g = 0; g < G; ++g) {
         LJMD_HIP(h, hipSetDevice(m->dev[g]));
         q[g] = next_events(m->eng[g]);
-        LJMD_CHILD(h, m->eng[g], enqueue_drift(m->eng[g], q[g]));
+        if (m->overlap) {
+            bool split_g = false;
+            LJMD_CHILD(h, m->eng[g], enqueue_drift_positions(m->eng[g], q[g], &split_g));
+            split = split && split_g;            // a re-sort step (the same on every rank) has already run all of K1
+        } else {
+            LJMD_CHILD(h, m->eng[g], enqueue_drift(m->eng[g], q[g]));
+        }
     }
-    LJMD_TRY(exchange_positions(h));
+    LJMD_TRY(exchange_positions(h, q));
+    if (split)
+        for (int g = 0; g < G; ++g) {
+            LJMD_HIP(h, hipSetDevice(m->dev[g]));
+            LJMD_CHILD(h, m->eng[g], enqueue_drift_velocities(m->eng[g]));
+        }
+    LJMD_TRY(await_positions(h));
     return enqueue_forces_all(h, true, q);
 }
 
@@ -216,7 +338,18 @@ int create(ljmd_t **out, int32_t n, double box_length, double dt, double rc, int
         m->dev.push_back(d);
     }
     const char *xm = std::getenv("LJMD_MULTI_EXCHANGE");
-    m->rccl = distinct && !(xm && std::strcmp(xm, "copy") == 0);
+    const std::string want = xm ? xm : "";
+    if (!want.empty() && want != "rccl" && want != "copy" && want != "host") {
+        destroy(h);
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "LJMD_MULTI_EXCHANGE=%s: expected rccl, copy or host", want.c_str());
+    }
+    if (want == "rccl" && !distinct) {
+        destroy(h);
+        return fail(nullptr, LJMD_ERR_INVALID_ARG,
+                    "LJMD_MULTI_EXCHANGE=rccl needs %d distinct devices (RCCL refuses two ranks on one device)", n_gpus);
+    }
+    m->xmode = want == "host" ? kHost : (want == "copy" || !distinct) ? kCopy : kRccl;
+    m->overlap = env_int("LJMD_OVERLAP_EXCHANGE", 1) != 0;
     for (int g = 0; g < n_gpus; ++g) {
         ljmd_t *e = nullptr;
         const int rc_ = ljmd_create(&e, n, box_length, dt, rc, precision_mode, m->dev[g], g, n_gpus);
@@ -244,32 +377,47 @@ int create(ljmd_t **out, int32_t n, double box_length, double dt, double rc, int
     h->dt = e0->dt; h->dt_half = e0->dt_half; h->dt_sq_half = e0->dt_sq_half;
     h->tail_e = e0->tail_e; h->tail_d = e0->tail_d; h->tail_dd = e0->tail_dd;
     auto body = [&]() -> int {
-        if (m->rccl) {
+        std::vector<hipEvent_t> *evs[] = {&m->ev_pos, &m->ev_got, &m->ev_force, &m->ev_fgot, &m->ev_hpos, &m->ev_hforce};
+        for (auto *v : evs) v->assign(n_gpus, nullptr);
+        m->xs.assign(n_gpus, nullptr);
+        m->h_xpos.assign(n_gpus, nullptr);
+        m->h_xforce.assign(n_gpus, nullptr);
+        for (int g = 0; g < n_gpus; ++g) {
+            ljmd_t *e = m->eng[g];
+            LJMD_HIP(h, hipSetDevice(m->dev[g]));
+            for (auto *v : evs) LJMD_HIP(h, hipEventCreateWithFlags(&(*v)[g], hipEventDisableTiming));
+            if (m->overlap) {
+                hipStream_t s = nullptr;
+                LJMD_HIP(h, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+                m->xs_owned.push_back(s);
+                m->xs[g] = s;
+            } else {
+                m->xs[g] = e->stream;
+            }
+            if (m->xmode == kCopy)
+                for (int k = 0; k < n_gpus; ++k)
+                    if (m->dev[k] != m->dev[g]) {
+                        const hipError_t pe = hipDeviceEnablePeerAccess(m->dev[k], 0);
+                        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                            return fail(h, LJMD_ERR_HIP, "peer access %d -> %d unavailable: %s", m->dev[g], m->dev[k],
+                                        hipGetErrorString(pe));
+                        (void)hipGetLastError();
+                    }
+            const size_t blk = 3 * (size_t)e->P * sizeof(double);
+            if (m->xmode != kRccl && needs_force_exchange(e) && !e->d_fall) LJMD_HIP(h, hipMalloc(&e->d_fall, blk * n_gpus));
+            if (m->xmode == kHost) {
+                // portable: every device's copy engine reads the staging of every rank
+                LJMD_HIP(h, hipHostMalloc(&m->h_xpos[g], blk, hipHostMallocPortable));
+                if (needs_force_exchange(e)) LJMD_HIP(h, hipHostMalloc(&m->h_xforce[g], blk * n_gpus, hipHostMallocPortable));
+            }
+        }
+        if (m->xmode == kRccl) {
             m->comm.assign(n_gpus, nullptr);
             const ncclResult_t r = ncclCommInitAll(m->comm.data(), n_gpus, m->dev.data());
             if (r != ncclSuccess) {
                 m->comm.clear();
                 return fail(h, LJMD_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", n_gpus, ncclGetErrorString(r));
             }
-            return LJMD_OK;
-        }
-        m->ev_pos.assign(n_gpus, nullptr);
-        m->ev_force.assign(n_gpus, nullptr);
-        for (int g = 0; g < n_gpus; ++g) {
-            LJMD_HIP(h, hipSetDevice(m->dev[g]));
-            LJMD_HIP(h, hipEventCreateWithFlags(&m->ev_pos[g], hipEventDisableTiming));
-            LJMD_HIP(h, hipEventCreateWithFlags(&m->ev_force[g], hipEventDisableTiming));
-            for (int k = 0; k < n_gpus; ++k)
-                if (m->dev[k] != m->dev[g]) {
-                    const hipError_t pe = hipDeviceEnablePeerAccess(m->dev[k], 0);
-                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
-                        return fail(h, LJMD_ERR_HIP, "peer access %d -> %d unavailable: %s", m->dev[g], m->dev[k],
-                                    hipGetErrorString(pe));
-                    (void)hipGetLastError();
-                }
-            ljmd_t *e = m->eng[g];
-            if (needs_force_exchange(e) && !e->d_fall)
-                LJMD_HIP(h, hipMalloc(&e->d_fall, 3 * (size_t)e->P * sizeof(double) * n_gpus));
         }
         return LJMD_OK;
     };
@@ -292,17 +440,29 @@ void destroy(ljmd_t *h)
             (void)hipSetDevice(m->dev[g]);
             if (m->eng[g]->stream) (void)hipStreamSynchronize(m->eng[g]->stream);
         }
+        for (hipStream_t x : m->xs_owned) (void)hipStreamSynchronize(x);
         for (ncclComm_t c : m->comm)
             if (c) (void)ncclCommDestroy(c);
-        for (size_t g = 0; g < m->ev_pos.size(); ++g) {
-            (void)hipSetDevice(m->dev[g]);
-            if (m->ev_pos[g]) (void)hipEventDestroy(m->ev_pos[g]);
-            if (m->ev_force[g]) (void)hipEventDestroy(m->ev_force[g]);
-        }
+        std::vector<hipEvent_t> *evs[] = {&m->ev_pos, &m->ev_got, &m->ev_force, &m->ev_fgot, &m->ev_hpos, &m->ev_hforce};
+        for (auto *v : evs)
+            for (size_t g = 0; g < v->size(); ++g)
+                if ((*v)[g]) {
+                    (void)hipSetDevice(m->dev[g]);
+                    (void)hipEventDestroy((*v)[g]);
+                }
+        for (hipStream_t x : m->xs_owned) (void)hipStreamDestroy(x);
+        for (double *p : m->h_xpos)
+            if (p) (void)hipHostFree(p);
+        for (double *p : m->h_xforce)
+            if (p) (void)hipHostFree(p);
         for (ljmd_t *e : m->eng) release(e);
         delete m;
     }
     delete h;
+}
+
+namespace {
+int migrate(ljmd_t *h);
 }
 
 int set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz, const double *vx, const double *vy,
@@ -310,10 +470,6 @@ int set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz, c
 {
     ljmd_multi *m = h->multi;
     for (int k = 0; k < h->n; ++k) m->owner[k] = k;
-    // the first deal is by position too (the caller's order may have nothing to do with space); with migration switched
-    // off, or one rank, the ranks own the caller's index ranges
-    if (m->G > 1 && m->migrate_every > 0)
-        std::stable_sort(m->owner.begin(), m->owner.end(), [rx](int32_t a_, int32_t b_) { return rx[a_] < rx[b_]; });
     m->steps_since_migration = 0;
     const double *rin[3] = {rx, ry, rz}, *vin[3] = {vx, vy, vz};
     to_engine_order(m, h->n, rin, 0);
@@ -328,7 +484,11 @@ int set_state(ljmd_t *h, const double *rx, const double *ry, const double *rz, c
     h->have_state = true;
     h->have_accel = false;
     h->poisoned = false;
-    return exchange_positions(h);      // every rank re-ordered its own block: share the new slot order
+    LJMD_TRY(exchange_positions_now(h));      // every rank re-ordered its own block: share the new slot order
+    // the first deal is by position too (the caller's order may have nothing to do with space); with migration switched
+    // off, or one rank, the ranks own the caller's index ranges
+    if (m->G > 1 && m->migrate_every > 0) return migrate(h);
+    return LJMD_OK;
 }
 
 int set_accel(ljmd_t *h, const double *ax, const double *ay, const double *az)
@@ -353,7 +513,7 @@ int set_unwrapped(ljmd_t *h, const double *ux, const double *uy, const double *u
 namespace {
 // the children's arrays (engine order, rank blocks) through `fetch`, then out[owner[k]] = engine[k]
 template <typename Fetch>
-int gather_by_owner(ljmd_t *h, double *const p[12], Fetch &&fetch)
+int gather_by_owner(ljmd_t *h, const std::vector<int32_t> &owner, double *const p[12], Fetch &&fetch)
 {
     ljmd_multi *m = h->multi;
     for (int k = 0; k < 12; ++k)
@@ -365,14 +525,14 @@ int gather_by_owner(ljmd_t *h, double *const p[12], Fetch &&fetch)
     }
     for (int k = 0; k < 12; ++k)
         if (p[k])
-            for (int i = 0; i < h->n; ++i) p[k][m->owner[i]] = m->stage[k][i];
+            for (int i = 0; i < h->n; ++i) p[k][owner[i]] = m->stage[k][i];
     return LJMD_OK;
 }
 }  // namespace
 
 int get_state(ljmd_t *h, double *const p[12])
 {
-    return gather_by_owner(h, p, [](ljmd_t *e, double *const q[12]) {
+    return gather_by_owner(h, h->multi->owner, p, [](ljmd_t *e, double *const q[12]) {
         return ljmd_get_state(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]);
     });
 }
@@ -399,48 +559,104 @@ int compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot)
 }
 
 namespace {
-// Deal the particles out again by position: engine order = sorted along the longest axis of the box-wide distribution
-// (rank g = the g-th n / G of them: a slab), every rank then k-d sorts its slab as after any set_state.  Through the
-// host: r, ru, v, a come down in engine order, are permuted, and go back up through the children's set_* calls.
+// Deal the particles out again by position, on the devices (ljmd.h: ljmd_migrate): every rank packs its ru, v, a and
+// ids, the blocks are all-gathered by the handle's exchange (RCCL / peer copies / host staging, on the engine streams:
+// a migration is rare and brackets itself with stream synchronisations), every rank computes the same k-d deal and keeps
+// its block.  The owner table follows from the ids the ranks report: new engine index g S + j holds the particle that
+// had engine index id before, and the ranks' ids start again at the identity (migrate_rebase).
 int migrate(ljmd_t *h)
 {
     ljmd_multi *m = h->multi;
-    const int n = h->n;
-    double *p[12];
-    for (int k = 0; k < 12; ++k) {
-        m->stage[k].resize(n);
-        p[k] = m->stage[k].data();
+    const int G = m->G, n = h->n;
+    for (int g = 0; g < G; ++g) {
+        ljmd_t *e = m->eng[g];
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        if (e->forces_pending) return fail(h, LJMD_ERR_STATE, "ownership migration: a step is half enqueued");
+        LJMD_CHILD(h, e, migrate_pack(e));
     }
-    for (ljmd_t *e : m->eng) {                                   // engine order, no owner mapping
-        double *q[12];
-        for (int k = 0; k < 12; ++k) q[k] = p[k] + (size_t)e->rank * e->S;
-        LJMD_CHILD(h, e, ljmd_get_state(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]));
+    for (int g = 0; g < G; ++g) {        // everything enqueued so far (the exchanges on xs[] included) is done
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_HIP(h, hipStreamSynchronize(m->eng[g]->stream));
+        LJMD_HIP(h, hipStreamSynchronize(m->xs[g]));
     }
-    int axis = 0;                                                // slabs along x (a cubic box: any axis serves)
-    std::vector<int32_t> order(n);
-    for (int k = 0; k < n; ++k) order[k] = k;
-    const double *key = p[axis];
-    std::stable_sort(order.begin(), order.end(), [key](int32_t a_, int32_t b_) { return key[a_] < key[b_]; });
-    std::vector<double> tmp(n);
-    for (int k = 0; k < 12; ++k) {
-        for (int i = 0; i < n; ++i) tmp[i] = p[k][order[i]];
-        m->stage[k].swap(tmp);
-        tmp.resize(n);
-        p[k] = m->stage[k].data();
+    const size_t blk = (size_t)kMigrateRows * m->eng[0]->P;
+    if (m->xmode == kRccl) {
+        ncclResult_t r = ncclGroupStart();
+        for (int g = 0; g < G && r == ncclSuccess; ++g) {
+            ljmd_t *e = m->eng[g];
+            r = ncclAllGather(migrate_buffer(e) + (size_t)g * blk, migrate_buffer(e), blk, ncclDouble, m->comm[g], m->xs[g]);
+        }
+        const ncclResult_t end = ncclGroupEnd();
+        if (r == ncclSuccess) r = end;
+        if (r != ncclSuccess) return nccl_failed(h, "all-gather (migration)", r);
+    } else {
+        std::vector<double *> hs(G, nullptr);
+        auto body = [&]() -> int {
+            if (m->xmode == kHost)
+                for (int g = 0; g < G; ++g) {
+                    LJMD_HIP(h, hipSetDevice(m->dev[g]));
+                    LJMD_HIP(h, hipHostMalloc(&hs[g], blk * sizeof(double), hipHostMallocPortable));
+                    LJMD_HIP(h, hipMemcpy(hs[g], migrate_buffer(m->eng[g]) + (size_t)g * blk, blk * sizeof(double),
+                                          hipMemcpyDeviceToHost));
+                }
+            for (int d = 0; d < G; ++d) {
+                LJMD_HIP(h, hipSetDevice(m->dev[d]));
+                for (int g = 0; g < G; ++g) {
+                    if (g == d) continue;
+                    double *dst = migrate_buffer(m->eng[d]) + (size_t)g * blk;
+                    if (m->xmode == kHost)
+                        LJMD_HIP(h, hipMemcpyAsync(dst, hs[g], blk * sizeof(double), hipMemcpyHostToDevice, m->xs[d]));
+                    else
+                        LJMD_HIP(h, hipMemcpyAsync(dst, migrate_buffer(m->eng[g]) + (size_t)g * blk, blk * sizeof(double),
+                                                   hipMemcpyDeviceToDevice, m->xs[d]));
+                }
+            }
+            for (int g = 0; g < G; ++g) {
+                LJMD_HIP(h, hipSetDevice(m->dev[g]));
+                LJMD_HIP(h, hipStreamSynchronize(m->xs[g]));
+            }
+            return LJMD_OK;
+        };
+        const int rc_ = body();
+        for (double *p : hs)
+            if (p) (void)hipHostFree(p);
+        if (rc_ != LJMD_OK) return rc_;
+    }
+    for (int g = 0; g < G; ++g) {
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_HIP(h, hipStreamSynchronize(m->xs[g]));
     }
     std::vector<int32_t> owner(n);
-    for (int i = 0; i < n; ++i) owner[i] = m->owner[order[i]];
-    m->owner.swap(owner);
-    for (ljmd_t *e : m->eng) {
-        LJMD_CHILD(h, e, ljmd_set_state(e, p[0], p[1], p[2], p[6], p[7], p[8]));
-        LJMD_CHILD(h, e, ljmd_set_unwrapped(e, p[3], p[4], p[5]));
-        LJMD_CHILD(h, e, ljmd_set_accel(e, p[9], p[10], p[11]));
+    for (int g = 0; g < G; ++g) {
+        ljmd_t *e = m->eng[g];
+        LJMD_HIP(h, hipSetDevice(m->dev[g]));
+        LJMD_CHILD(h, e, migrate_deal(e));                   // synchronises the rank's stream; e->h_gid0 is valid
+        for (int j = 0; j < e->S; ++j) {
+            const int id = e->h_gid0[j];
+            if (id < 0 || id >= n) return fail(h, LJMD_ERR_STATE, "ownership migration: rank %d reports particle id %d", g, id);
+            owner[(size_t)g * e->S + j] = m->owner[id];
+        }
+        LJMD_CHILD(h, e, migrate_rebase(e));
     }
+    m->owner.swap(owner);
     m->steps_since_migration = 0;
     ++m->migrations;
-    return exchange_positions(h);
+    return exchange_positions_now(h);
 }
 }  // namespace
+
+int migrate_now(ljmd_t *h)
+{
+    if (!h->have_state) return fail(h, LJMD_ERR_STATE, "ljmd_migrate: no state has been set");
+    if (h->multi->G == 1) return LJMD_OK;
+    return migrate(h);
+}
+
+ljmd_t *rank_engine(ljmd_t *h, int32_t rank)
+{
+    ljmd_multi *m = h->multi;
+    return (rank >= 0 && rank < m->G) ? m->eng[rank] : nullptr;
+}
 
 int32_t migrations(const ljmd_t *h) { return h->multi->migrations; }
 
@@ -448,11 +664,9 @@ int enqueue_steps(ljmd_t *h, int32_t nsteps, bool sampled)
 {
     {
         ljmd_multi *m = h->multi;
-        bool snap = false;
-        for (const ljmd_t *e : m->eng) snap = snap || e->snap_in_flight;
-        // only at a quiet point: no step records waiting to be collected (ljmd_set_state restarts the children's rings),
-        // no snapshot on its way out (it is delivered through the owner table of its own moment)
-        if (m->migrate_every > 0 && m->steps_since_migration >= m->migrate_every && pending(h) == 0 && !snap && h->have_accel)
+        // between two steps; step records waiting to be collected stay where they are (per-rank sums of finished steps)
+        // and a snapshot in flight is delivered through the owner table of its own moment (owner_snap)
+        if (m->G > 1 && m->migrate_every > 0 && m->steps_since_migration >= m->migrate_every && h->have_accel)
             LJMD_TRY(migrate(h));
         m->steps_since_migration += nsteps;
     }
@@ -481,13 +695,15 @@ int collect_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, double 
 int snapshot_begin(ljmd_t *h)
 {
     for (ljmd_t *e : h->multi->eng) LJMD_CHILD(h, e, ljmd_snapshot_begin(e));
+    h->multi->owner_snap = h->multi->owner;
     return LJMD_OK;
 }
 
 int snapshot_end(ljmd_t *h, double *const p[12])
 {
-    // (no migration happens while a snapshot is in flight, so `owner` is still the one of snapshot_begin)
-    return gather_by_owner(h, p, [](ljmd_t *e, double *const q[12]) {
+    // the ranks deliver the engine order of snapshot_begin (their own slot permutation of that moment); migrations since
+    // then have changed `owner`, not `owner_snap`
+    return gather_by_owner(h, h->multi->owner_snap, p, [](ljmd_t *e, double *const q[12]) {
         return ljmd_snapshot_end(e, q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11]);
     });
 }
@@ -542,7 +758,7 @@ const char *pair_kernel_name(const ljmd_t *h) { return ljmd_pair_kernel_name(h->
 int32_t comm_size(const ljmd_t *h)
 {
     const ljmd_multi *m = h->multi;
-    if (!m->rccl || m->comm.empty() || !m->comm[0]) return 0;
+    if (m->xmode != kRccl || m->comm.empty() || !m->comm[0]) return 0;
     int count = 0;
     return ncclCommCount(m->comm[0], &count) == ncclSuccess ? count : 0;
 }

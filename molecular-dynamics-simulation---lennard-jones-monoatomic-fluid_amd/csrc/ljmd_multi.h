@@ -18,7 +18,9 @@ int get_state(ljmd_t *h, double *const p[12]);
 int compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot);
 int enqueue_steps(ljmd_t *h, int32_t nsteps, bool sampled);
 int set_observables(ljmd_t *h, bool on);
-int32_t migrations(const ljmd_t *h);      // ownership migrations done so far (tests)
+int32_t migrations(const ljmd_t *h);      // ownership migrations done so far
+int migrate_now(ljmd_t *h);               // ljmd_migrate on a multi-device handle
+ljmd_t *rank_engine(ljmd_t *h, int32_t rank);   // NULL when out of range
 int collect_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, double *d_epot, double *dd_epot);
 int snapshot_begin(ljmd_t *h);
 int snapshot_end(ljmd_t *h, double *const p[12]);

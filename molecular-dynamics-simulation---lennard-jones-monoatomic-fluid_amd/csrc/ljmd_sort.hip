@@ -124,6 +124,131 @@ hipError_t kd_level(void *temp, size_t temp_bytes, const double *coord_axis, dou
                                               kCoordBits + segbits, s);
 }
 
+// ---- ownership migration (multi-GPU): the particles of ALL ranks dealt out again by position -----------------------
+// Every rank holds all n positions (exchange buffer [G][3][P], real particles in slots 0..S-1 of each block) and, after
+// one all-gather, everybody's ru, v, a and particle ids (migration buffer [G][10][P]).  The deal is a k-d split of the
+// n particles into G segments of exactly S = n / G: the same composite-key radix sort as above, over storage indices
+// g * P + s, computed redundantly and identically (stable sort, same input bits) by every rank; rank r then takes
+// segment r.  Blocks instead of slabs: a rank's surface, and with it the number of column tiles its rows meet at the
+// cutoff, does not grow with G.
+__global__ __launch_bounds__(kBlock) void iota_blocked_kernel(int *idx, int n, int S, int P)
+{
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < n) idx[k] = (k / S) * P + k % S;
+}
+
+__global__ __launch_bounds__(kBlock) void kd_keys_blocked_kernel(const double *pos, int axis, int P, const int *idx,
+                                                                 unsigned long long *keys, const int *seg_offsets, int nseg,
+                                                                 int n, double scale)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = nseg;                              // largest j with seg_offsets[j] <= i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int st = idx[i], g = st / P, sl = st - g * P;
+    const double x = pos[(size_t)g * 3 * P + (size_t)axis * P + sl] * scale;
+    const unsigned long long q = (unsigned long long)fmin(fmax(x, 0.0), (double)((1u << kCoordBits) - 1));
+    keys[i] = ((unsigned long long)lo << kCoordBits) | q;
+}
+
+// own block of the migration buffer: ru, v, a and the particle id of every slot (id < 0: padding)
+__global__ __launch_bounds__(kBlock) void migrate_pack_kernel(const double *ru, const double *v, const double *a,
+                                                              const int *perm, const int *gid0, double *block, int S, int P)
+{
+    const int s = blockIdx.x * kBlock + threadIdx.x;
+    if (s >= P) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        block[(size_t)k * P + s] = ru[(size_t)k * P + s];
+        block[(size_t)(3 + k) * P + s] = v[(size_t)k * P + s];
+        block[(size_t)(6 + k) * P + s] = a[(size_t)k * P + s];
+    }
+    const int o = perm[s];
+    block[(size_t)9 * P + s] = (s < S && o < S) ? (double)gid0[o] : -1.0;     // ids < 2^31: exact in a double
+}
+
+// the rank's new members, in the order of its segment of the deal: positions into a scratch block, ru, v, a and the ids
+// into place (their sources are in the migration buffer); padding as after ljmd_set_state
+__global__ __launch_bounds__(kBlock) void migrate_select_kernel(const double *pos_all, const double *mig_all, const int *mine,
+                                                                double *new_pos, double *ru, double *v, double *a, int *gid0,
+                                                                int S, int P)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= P) return;
+    if (j >= S) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            new_pos[(size_t)k * P + j] = __builtin_nan("");
+            ru[(size_t)k * P + j] = __builtin_nan("");
+            v[(size_t)k * P + j] = 0.0;
+            a[(size_t)k * P + j] = 0.0;
+        }
+        gid0[j] = -1;
+        return;
+    }
+    const int st = mine[j], g = st / P, sl = st - g * P;
+    const double *pb = pos_all + (size_t)g * 3 * P + sl;
+    const double *mb = mig_all + (size_t)g * 10 * P + sl;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        new_pos[(size_t)k * P + j] = pb[(size_t)k * P];
+        ru[(size_t)k * P + j] = mb[(size_t)k * P];
+        v[(size_t)k * P + j] = mb[(size_t)(3 + k) * P];
+        a[(size_t)k * P + j] = mb[(size_t)(6 + k) * P];
+    }
+    gid0[j] = (int)mb[(size_t)9 * P];
+}
+
+__global__ __launch_bounds__(kBlock) void iota_offset_kernel(int *idx, int count, int P, int offset)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < P) idx[i] = i < count ? offset + i : -1;
+}
+
+hipError_t launch_iota_blocked(int *idx, int n, int S, int P, hipStream_t s)
+{
+    hipLaunchKernelGGL(iota_blocked_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, idx, n, S, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_iota_offset(int *idx, int count, int P, int offset, hipStream_t s)
+{
+    hipLaunchKernelGGL(iota_offset_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, idx, count, P, offset);
+    return hipGetLastError();
+}
+
+hipError_t kd_level_blocked(void *temp, size_t temp_bytes, const double *pos, int axis, int P, double L,
+                            unsigned long long *keys, unsigned long long *keys_out, int *idx, int *idx_out, int n, int nseg,
+                            const int *seg_offsets, hipStream_t s)
+{
+    hipLaunchKernelGGL(kd_keys_blocked_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pos, axis, P, idx, keys,
+                       seg_offsets, nseg, n, (double)(1u << kCoordBits) / L);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int segbits = 1;
+    while ((1 << segbits) < nseg) ++segbits;
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_out, idx, idx_out, n, 0, kCoordBits + segbits, s);
+}
+
+hipError_t launch_migrate_pack(const double *ru, const double *v, const double *a, const int *perm, const int *gid0,
+                               double *block, int S, int P, hipStream_t s)
+{
+    hipLaunchKernelGGL(migrate_pack_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ru, v, a, perm, gid0, block,
+                       S, P);
+    return hipGetLastError();
+}
+
+hipError_t launch_migrate_select(const double *pos_all, const double *mig_all, const int *mine, double *new_pos, double *ru,
+                                 double *v, double *a, int *gid0, int S, int P, hipStream_t s)
+{
+    hipLaunchKernelGGL(migrate_select_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pos_all, mig_all, mine,
+                       new_pos, ru, v, a, gid0, S, P);
+    return hipGetLastError();
+}
+
 size_t sort_temp_bytes(int count)
 {
     size_t bytes = 0;

@@ -59,10 +59,15 @@ class ShardedSimulation:
     partial accelerations are staged through pinned host memory and gloo; compute stays on the GPU.
     Slower (PCIe + TCP per step), reported as such by bench.py."""
 
-    def __init__(self, engine, rank: int, world: int, group=None, exchange: str = "rccl"):
+    def __init__(self, engine, rank: int, world: int, group=None, exchange: str = "rccl", migrate_every: int = 2000):
         self.engine = engine
         self.rank, self.world, self.group = rank, world, group
         self.exchange = exchange
+        # ownership migration (include/ljmd.h: ljmd_migrate): at start() -- the caller's index ranges may have nothing to
+        # do with space -- and then every `migrate_every` steps (0 = never; the ranks then own index ranges for good)
+        self.migrate_every = migrate_every
+        self.steps_since_migration = 0
+        self.observables = True
         if world > 1:
             import torch.distributed as dist
             self.dist = dist
@@ -133,12 +138,44 @@ class ShardedSimulation:
                 c[s] = val
         return tuple(cols)
 
+    # -- ownership migration ------------------------------------------------------------
+    def migrate(self) -> None:
+        """Every rank, between two steps: the particles are dealt out again by position, on the devices.  With the
+        library's RCCL exchange one call does it all; the host-staged form moves the G blocks of the migration buffer
+        through gloo between the two device phases and repeats the position exchange."""
+        if self.world == 1:
+            return
+        if self.exchange == "host":
+            import torch
+            self.engine.migrate_pack()
+            ptr, total, off, cnt = self.engine.migrate_buffer()
+            full = torch.empty(total, dtype=torch.float64)
+            own = full[off:off + cnt]
+            self.engine.memcpy(own.data_ptr(), ptr + 8 * off, 8 * cnt, 2)
+            self.dist.all_gather_into_tensor(full, own, group=self.group)
+            self.engine.memcpy(ptr, full.data_ptr(), 8 * total, 1)
+            self.engine.migrate_deal()
+            self._host_allgather()
+        else:
+            self.engine.migrate()
+        self.steps_since_migration = 0
+
+    def particle_ids(self) -> np.ndarray:
+        """index, in the arrays given to start(), of the particle at each position of this rank's get_state arrays"""
+        return self.engine.particle_ids()
+
+    def set_observables(self, on: bool) -> None:
+        self.observables = bool(on)
+        self.engine.set_observables(self.observables)
+
     # -- the reference's call sequence ------------------------------------------------
     def start(self, r: np.ndarray, v: np.ndarray):
         """Every rank passes the same global r[3, N], v[3, N] (md_simulation_program.f90:221-236).
         -> (epot, d_epot, dd_epot) of the t = 0 force evaluation."""
         self.engine.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         self.exchange_positions()      # every rank re-orders its own block at set_state: share the new order
+        if self.migrate_every > 0:
+            self.migrate()             # the first deal is by position too
         self._finish(False)
         parts = self._gather_partials(self.engine.read_partials(1))
         e, _k, d, dd = self._combine(parts)
@@ -147,6 +184,9 @@ class ShardedSimulation:
     def enqueue_steps(self, nsteps: int, sampled: bool = False) -> None:
         """nsteps x {drift+kick1 | all-gather | forces+kick2}; no host synchronisation.
         sampled: potential-energy sums on the last step only (ljmd_enqueue_steps_sampled / ljmd_set_observables)."""
+        if self.migrate_every > 0 and self.steps_since_migration >= self.migrate_every:
+            self.migrate()
+        self.steps_since_migration += nsteps
         for s in range(nsteps):
             if sampled:
                 self.engine.set_observables(s == nsteps - 1)
@@ -154,7 +194,7 @@ class ShardedSimulation:
             self.exchange_positions()
             self._finish(True)
         if sampled:
-            self.engine.set_observables(True)
+            self.engine.set_observables(self.observables)     # what the caller had chosen, as the C paths do
 
     def collect(self, nsteps: int):
         """-> (epot, ekin, d_epot, dd_epot) arrays of the last nsteps enqueued steps."""

@@ -191,8 +191,33 @@ class Engine:
         self._ck(fn(self._h, nsteps))
 
     def migrations(self) -> int:
-        """multi-device handle: ownership migrations so far (LJMD_MULTI_MIGRATE_EVERY)"""
+        """ownership migrations so far (multi-device handle: also the automatic ones, LJMD_MULTI_MIGRATE_EVERY)"""
         return int(self._lib.ljmd_multi_migrations(self._h))
+
+    # -- ownership migration (multi-GPU; include/ljmd.h: ljmd_migrate) ------------------------
+    def migrate(self) -> None:
+        """deal the particles out to the ranks again by position, on the devices, collectives included (multi-device
+        handle, or a rank engine with an RCCL communicator: every rank calls it at the same step)"""
+        self._ck(self._lib.ljmd_migrate(self._h))
+
+    def migrate_pack(self) -> None:
+        self._ck(self._lib.ljmd_migrate_pack(self._h))
+
+    def migrate_buffer(self):
+        """-> (device address, total doubles, own offset, own count) of the migration buffer"""
+        tot, off, cnt = C.c_int64(), C.c_int64(), C.c_int64()
+        p = self._lib.ljmd_migrate_buffer(self._h, C.byref(tot), C.byref(off), C.byref(cnt))
+        return p, tot.value, off.value, cnt.value
+
+    def migrate_deal(self) -> None:
+        self._ck(self._lib.ljmd_migrate_deal(self._h))
+
+    def particle_ids(self) -> np.ndarray:
+        """ids[j] = index, in the arrays given to set_state, of the particle at position j of this engine's arrays"""
+        n = self.shard if self.n_ranks > 1 else self.params.n
+        ids = np.empty(n, dtype=np.int32)
+        self._ck(self._lib.ljmd_particle_ids(self._h, ids.ctypes.data_as(_lib.c_int32_p)))
+        return ids
 
     def set_observables(self, on: bool) -> None:
         """phase API (sharded engines): forces-only force evaluations while off"""
@@ -307,6 +332,18 @@ class Engine:
         self._ck(self._lib.ljmd_profile_read_ex(self._h, ms, lo, C.byref(c)))
         out = {"pair_ms": ms[0], "geometry_ms": ms[1], "drift_ms": ms[2], "reduce_ms": ms[3], "launches": c.value}
         out.update({"pair_ms_min": lo[0], "geometry_ms_min": lo[1], "drift_ms_min": lo[2], "reduce_ms_min": lo[3]})
+        return out
+
+    def profile_read_rank(self, rank: int) -> dict:
+        """ljmd_profile_read_rank: the same per rank engine, plus the two exchanges of a multi-GPU step
+        ('pos_exchange_ms': position all-gather, 'force_exchange_ms': reduce-scatter / all-to-all)"""
+        ms, lo = (C.c_double * 6)(), (C.c_double * 6)()
+        c = C.c_int32()
+        self._ck(self._lib.ljmd_profile_read_rank(self._h, rank, ms, lo, C.byref(c)))
+        names = ("pair_ms", "geometry_ms", "drift_ms", "reduce_ms", "pos_exchange_ms", "force_exchange_ms")
+        out = {k: ms[i] for i, k in enumerate(names)}
+        out.update({k + "_min": lo[i] for i, k in enumerate(names)})
+        out["launches"] = c.value
         return out
 
 

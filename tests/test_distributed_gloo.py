@@ -32,6 +32,9 @@ class OracleShardEngine:
         self.S = params.n // world
         self.buf = np.zeros((world, 3, self.S))          # exchange buffer, shard-blocked SoA
         self.records = []
+        self.ids = np.arange(rank * self.S, (rank + 1) * self.S)
+        self.mig = np.zeros((world, 10, self.S))         # migration buffer: ru, v, a, id per slot
+        self.observables = []
 
     # ---- what ShardedSimulation needs -------------------------------------------------
     def allgather_positions(self):
@@ -65,8 +68,45 @@ class OracleShardEngine:
         assert not getattr(self, "comm_ready", False), "communicator initialised twice"
         self.comm_ready = True
 
+    # -- ownership migration protocol (include/ljmd.h: ljmd_migrate*), any balanced deal by position will do here ----
+    def migrate_pack(self):
+        self.mig[self.rank] = np.concatenate([self.ru, self.v, self.a, self.ids[None].astype(float)])
+
+    def migrate_buffer(self):
+        cnt = 10 * self.S
+        return self.mig.ctypes.data, self.mig.size, self.rank * cnt, cnt
+
+    def migrate_deal(self):
+        S = self.S
+        order = np.argsort(self.buf[:, 0, :].reshape(-1), kind="stable")      # slabs along x
+        mine = order[self.rank * S:(self.rank + 1) * S]
+        g, s = mine // S, mine % S
+        newpos = self.buf[g, :, s].T.copy()
+        self.ru, self.v, self.a = (self.mig[g, 3 * k:3 * k + 3, s].T.copy() for k in range(3))
+        self.ids = self.mig[g, 9, s].astype(np.int64)
+        self.buf[self.rank] = newpos
+        self.migrations = getattr(self, "migrations", 0) + 1
+
+    def migrate(self):
+        """the RCCL form: the library does both all-gathers itself"""
+        import torch
+        import torch.distributed as dist
+        self.migrate_pack()
+        full = torch.from_numpy(self.mig.reshape(-1))
+        cnt = 10 * self.S
+        dist.all_gather_into_tensor(full, full[self.rank * cnt:(self.rank + 1) * cnt].clone())
+        self.migrate_deal()
+        self.allgather_positions()
+
+    def particle_ids(self):
+        return self.ids.copy()
+
+    def set_observables(self, on):
+        self.observables.append(bool(on))
+
     def set_state(self, rx, ry, rz, vx, vy, vz):
         S, g = self.S, self.rank
+        self.ids = np.arange(g * S, (g + 1) * S)
         for r in range(self.world):
             self.buf[r] = np.stack([rx[r * S:(r + 1) * S], ry[r * S:(r + 1) * S], rz[r * S:(r + 1) * S]])
         sl = slice(g * S, (g + 1) * S)
@@ -123,7 +163,7 @@ class OracleShardEngine:
                 24.0 * (26.0 * s12 - 7.0 * s6) + tdd)
 
 
-def _worker(rank, world, port, n, nsteps, outdir, exchange="rccl"):
+def _worker(rank, world, port, n, nsteps, outdir, exchange="rccl", migrate_every=0):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -137,11 +177,22 @@ def _worker(rank, world, port, n, nsteps, outdir, exchange="rccl"):
         assert eng.comm_ready
         eng.comm_ready = False
         assert distributed.try_bootstrap_rccl(eng, rank, world)
-        sim = distributed.ShardedSimulation(eng, rank, world, exchange=exchange)
+        sim = distributed.ShardedSimulation(eng, rank, world, exchange=exchange, migrate_every=migrate_every)
         e0, d0, dd0 = sim.start(r, v)
-        e, k, d, dd = sim.run(nsteps)
+        if migrate_every:
+            # two segments, the second one sampled: a migration at start(), one before the second segment, and the
+            # caller's observables switch survives the sampled segment
+            sim.set_observables(False)
+            h = nsteps // 2
+            parts = [sim.run(h)]
+            sim.enqueue_steps(nsteps - h, sampled=True)
+            parts.append(sim.collect(nsteps - h))
+            e, k, d, dd = (np.concatenate([a[c] for a in parts]) for c in range(4))
+            assert eng.migrations == 2 and eng.observables[-1] is False and eng.observables[-2] is True
+        else:
+            e, k, d, dd = sim.run(nsteps)
         np.savez(Path(outdir) / f"rank{rank}.npz", t0=np.array([e0, d0, dd0]), sc=np.stack([e, k, d, dd], axis=1),
-                 buf=eng.buf, v=eng.v, ru=eng.ru, a=eng.a)
+                 buf=eng.buf, v=eng.v, ru=eng.ru, a=eng.a, ids=sim.particle_ids())
     finally:
         dist.destroy_process_group()
 
@@ -152,14 +203,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "rccl"), (2, "host")])
-def test_sharded_run_matches_single_process_oracle(tmp_path, oracle, world, exchange):
+@pytest.mark.parametrize("world,exchange,migrate_every", [(2, "rccl", 0), (2, "host", 0), (2, "rccl", 6), (2, "host", 6)])
+def test_sharded_run_matches_single_process_oracle(tmp_path, oracle, world, exchange, migrate_every):
+    """migrate_every > 0: the particles are dealt out by position at start() and again before the second segment -- the
+    ranks then own SETS of particles, identified by particle_ids(), and the exchange buffer is in the order of the deal"""
     import torch.multiprocessing as mp
     from ljmd_amd import synthetic
     n, nsteps = 432, 12
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nsteps, str(tmp_path), exchange))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, nsteps, str(tmp_path), exchange, migrate_every))
              for r in range(world)]
     for p_ in procs:
         p_.start()
@@ -183,11 +236,14 @@ def test_sharded_run_matches_single_process_oracle(tmp_path, oracle, world, exch
         assert np.array_equal(out["t0"], res[0]["t0"]) and np.array_equal(out["sc"], res[0]["sc"])
         assert np.allclose(out["t0"], [e0, d0, dd0], rtol=1e-12, atol=0)
         assert np.max(np.abs(out["sc"] - sc) / np.abs(sc)) < 1e-10
-        # after the last all-gather every rank holds ALL positions, in shard-blocked order
+        # after the last all-gather every rank holds ALL positions, in shard-blocked order of the current owners
         allpos = np.stack([np.concatenate([out["buf"][g][k] for g in range(world)]) for k in range(3)])
-        assert np.max(np.abs(allpos - np.stack([st["rx"], st["ry"], st["rz"]]))) < 1e-11
+        owners = np.concatenate([res[g]["ids"] for g in range(world)])
+        assert np.array_equal(np.sort(owners), np.arange(n))                  # every particle owned exactly once
+        assert np.max(np.abs(allpos - np.stack([st["rx"], st["ry"], st["rz"]])[:, owners])) < 1e-11
         assert np.array_equal(out["buf"], res[0]["buf"])
-        sl = slice(rank * S, (rank + 1) * S)
+        sl = out["ids"]
+        assert migrate_every or np.array_equal(sl, np.arange(rank * S, (rank + 1) * S))
         assert np.max(np.abs(out["v"] - np.stack([st["vx"][sl], st["vy"][sl], st["vz"][sl]]))) < 1e-10
         assert np.max(np.abs(out["ru"] - np.stack([st["ux"][sl], st["uy"][sl], st["uz"][sl]]))) < 1e-11
 
@@ -205,27 +261,3 @@ def test_world_size_one_needs_no_process_group(oracle):
     assert abs(e0 - ref[0]) < 1e-12 * abs(ref[0])
     e, k, d, dd = sim.run(3)
     assert e.shape == (3,) and np.all(np.isfinite(k))
-
-
-def test_bench_self_launch_spawns_ranks_and_relays_their_exit_code():
-    """`python bench.py --gpus 2` with no launcher environment must start its two ranks itself (a child
-    torch.distributed.run, spawned before the parent touches torch or HIP) and exit with the child's code.  Without a
-    GPU the ranks fail loudly in ljmd_create (there is no CPU path), so here: non-zero exit, no JSON line on stdout,
-    the library's error text relayed on stderr.  (The success path is tests/test_gpu_sharded.py on the GPU box.)"""
-    import os
-    import subprocess
-    import sys
-    from conftest import ROOT
-    import ljmd_amd
-    from ljmd_amd import _lib
-    if _lib.load().ljmd_device_count() > 0:
-        pytest.skip("a HIP device is present: covered by tests/test_gpu_sharded.py")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--particles", "4096", "--no-cpu-baseline", "--no-liquid"], env=env, capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode != 0
-    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert "no launcher environment: starting" in out.stderr
-    assert "torch.distributed.run" in out.stderr and "--nproc-per-node=2" in out.stderr
-    assert "no HIP device available" in out.stderr

@@ -30,7 +30,7 @@ for f in ("fakehip_kernel_launches", "fakehip_copies", "fakehip_collectives"):
 lib = _lib.load()
 assert lib.ljmd_device_count() == 8
 
-def drive(eng, r, v, steps):
+def drive(eng, r, v, steps, ranks=1):
     eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
     eng.compute_forces()
     eng.kinetic_energy()
@@ -43,6 +43,12 @@ def drive(eng, r, v, steps):
     eng.verlet_steps(3)
     eng.enqueue_steps(6, sampled=True); eng.collect_steps(6)      # forces-only steps, sums on the last one
     eng.advance(4)
+    # the production driver's order around a sample: begin, next segment, end -- with a migration due in between
+    eng.snapshot_begin(); eng.migrate(); eng.enqueue_steps(4); eng.snapshot_end(); eng.collect_steps(4)
+    eng.profile_enable(True); eng.enqueue_steps(3); eng.collect_steps(3)
+    prof = [eng.profile_read_rank(g) for g in range(ranks)]
+    assert all(q["launches"] == 3 for q in prof), prof
+    eng.profile_enable(False)
     return st
 
 # single engines: gather kernel sizes, Newton-3 with 1 / 2 / 4 tiles per row group, padded shards, mixed precision
@@ -63,13 +69,18 @@ for n, devices, env in ((16384, [0, 1], {}), (16384, [0, 1, 2, 3], {}), (32768, 
                         (3000, [0, 1, 2], {"LJMD_N3_MIN_N": "1"}), (4096, [2, 5], {"LJMD_N3": "0"}),
                         (16384, [0, 1, 2, 3], {"LJMD_MULTI_EXCHANGE": "copy"}), (16384, [0, 0, 0, 0], {}),
                         (16384, [0, 1, 2, 3], {"LJMD_MULTI_MIGRATE_EVERY": "5"}),     # ownership migration between the segments
+                        (16384, [0, 1, 2, 3], {"LJMD_MULTI_EXCHANGE": "host", "LJMD_MULTI_MIGRATE_EVERY": "7"}),   # pinned-host staging
+                        (4096, [1, 3], {"LJMD_N3": "0", "LJMD_MULTI_EXCHANGE": "host"}),
+                        (16384, [0, 1, 2, 3], {"LJMD_OVERLAP_EXCHANGE": "0"}),         # exchanges on the engine streams
+                        (12288, [0, 1, 2], {"LJMD_MULTI_EXCHANGE": "copy", "LJMD_N3_MIN_N": "1", "LJMD_MULTI_MIGRATE_EVERY": "3"}),
                         (24576, [0, 1, 2], {"LJMD_N3_ROW_TILES": "4", "LJMD_N3_WG_WAVES": "2", "LJMD_N3_MIN_N": "1"})):
     os.environ.update(env)
     p, r, v = synthetic.make_config(n, seed=5)
     with Engine(p, devices=devices) as eng:
-        rccl = len(set(devices)) == len(devices) and env.get("LJMD_MULTI_EXCHANGE") != "copy"
+        rccl = len(set(devices)) == len(devices) and env.get("LJMD_MULTI_EXCHANGE") not in ("copy", "host")
         assert eng.comm_size() == (len(devices) if rccl else 0)
-        st = drive(eng, r, v, 25)
+        st = drive(eng, r, v, 25, ranks=len(devices))
+        assert eng.migrations() >= 2                    # at set_state and the explicit one, plus the periodic ones
         assert all(a.shape == (n,) for k in ("r", "ru", "v", "a") for a in st[k])
     for k in env:
         del os.environ[k]
@@ -105,6 +116,18 @@ for _ in range(3):
         e.step_forces()
     for e in engines:
         e.step_finish()
+# ownership migration through the split-phase entry points, the caller moving the blocks
+for e in engines:
+    e.migrate_pack()
+bufs = [e.migrate_buffer() for e in engines]
+for d, e in enumerate(engines):
+    for g in range(4):
+        if g != d:
+            ptr_g, total, off_g, cnt = bufs[g]
+            e.memcpy(bufs[d][0] + 8 * off_g, ptr_g + 8 * off_g, 8 * cnt, 3)
+for e in engines:
+    e.migrate_deal()
+    assert e.particle_ids().shape == (2048,) and e.migrations() == 1
 for e in engines:
     e.read_partials(4)
     e.close()
