@@ -729,12 +729,14 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             const int tn = next_kept(t + 1, cn, dn, ln, blkn, mbn, descn);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t has landed (issued one tile ago)
             __builtin_amdgcn_wave_barrier();
-            double jx = 0.0, jy = 0.0, jz = 0.0;
+            double jx = 0.0, jy = 0.0, jz = 0.0, p12 = 0.0, p6 = 0.0;
             double *pk_cur = cur ? parked_all[0][1] : parked_all[0][0];
             double *pk_next = cur ? parked_all[0][0] : parked_all[0][1];
             n3_tile_pass<RT, W, true, ENERGY>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, pk_cur,
                                       [&]() { if (tn < nt) tile_to_lds_async(a, lane, cn, pk_next); },
-                                      jx, jy, jz, s12, s6);
+                                      jx, jy, jz, p12, p6);
+            s12 += p12;
+            s6 += p6;
             double *o = a.slab_j + blk * (3 * kTile) + lane;
             o[0] = jx;
             o[kTile] = jy;
@@ -753,9 +755,16 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             const unsigned mb = tile_of(t, c, d, l, blk, desc);
             const bool have = mb != 0;
             double jx = 0.0, jy = 0.0, jz = 0.0;
-            if (have)
+            if (have) {
+                // two-level energy sums: a pass (<= 256 terms per lane) sums into its own pair, which is added to the
+                // work item's running pair once -- the rounding error of a lane's sum no longer grows with the number of
+                // column tiles a work item walks (LJMD_N3_TARGET_WAVES, n), 2 additions per 64 rotation steps
+                double p12 = 0.0, p6 = 0.0;
                 n3_tile_pass<RT, W, false, ENERGY>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, parked,
-                                           []() {}, jx, jy, jz, s12, s6);
+                                           []() {}, jx, jy, jz, p12, p6);
+                s12 += p12;
+                s6 += p6;
+            }
             if constexpr (W == 1) {
                 if (have) {
                     double *o = a.slab_j + blk * (3 * kTile) + lane;

@@ -60,9 +60,32 @@ def _emulated_reduce_scatter(engines):
     assert hip.hipDeviceSynchronize() == 0
 
 
-@pytest.mark.parametrize("n,G,n3", [(4096, 2, False), (4096, 4, False), (3000, 3, False),
-                                    (4096, 2, True), (4096, 4, True), (3000, 3, True), (8192, 8, True)])
-def test_sharded_engines_match_single_engine(n, G, n3, monkeypatch):
+def _emulated_migration(engines):
+    """ljmd_migrate with the caller as the collective: pack, every block of the migration buffer copied into every other
+    rank's buffer device to device, deal, and the position exchange again."""
+    hip = _hip()
+    for e in engines:
+        e.migrate_pack()
+    for e in engines:
+        e.synchronize()
+    bufs = [e.migrate_buffer() for e in engines]
+    for g, (sp, _tot, off, cnt) in enumerate(bufs):
+        for d, dst in enumerate(engines):
+            if d != g:
+                assert hip.hipMemcpy(bufs[d][0] + 8 * off, sp + 8 * off, 8 * cnt, 3) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    for e in engines:
+        e.migrate_deal()
+    _emulated_allgather(engines)
+
+
+@pytest.mark.parametrize("n,G,n3,migrate", [(4096, 2, False, False), (4096, 4, False, True), (3000, 3, False, False),
+                                            (4096, 2, True, True), (4096, 4, True, False), (3000, 3, True, True),
+                                            (8192, 8, True, True), (8192, 8, True, False)])
+def test_sharded_engines_match_single_engine(n, G, n3, migrate, monkeypatch):
+    """migrate: the ownership migration of the one-process-per-GPU form (ljmd_migrate_pack / _deal around the caller's
+    exchange) right after set_state and again after 8 steps -- the ranks then own k-d blocks of particles instead of
+    index ranges, identified by ljmd_particle_ids; same bounds against the single engine."""
     monkeypatch.setenv("LJMD_N3_MIN_N", "1" if n3 else "100000000")
     p, r, v = synthetic.make_config(n, seed=5)
     nsteps = 15
@@ -78,6 +101,8 @@ def test_sharded_engines_match_single_engine(n, G, n3, monkeypatch):
             e.force_buffers(True)                      # the test performs the force exchange
             e.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         _emulated_allgather(engines)                   # every rank re-ordered its own block
+        if migrate:
+            _emulated_migration(engines)
         for e in engines:
             e.step_forces()
         _emulated_reduce_scatter(engines)
@@ -86,7 +111,9 @@ def test_sharded_engines_match_single_engine(n, G, n3, monkeypatch):
         parts0 = np.stack([e.read_partials(1)[0] for e in engines])
         t0 = engines[0].combine_scalars(parts0)
         assert np.allclose([t0[0], t0[2], t0[3]], e0, rtol=1e-13, atol=0)
-        for _ in range(nsteps):
+        for step in range(nsteps):
+            if migrate and step == 8:
+                _emulated_migration(engines)           # step records of the first 8 steps stay pending across it
             for e in engines:
                 e.step_begin()
             _emulated_allgather(engines)
@@ -99,14 +126,38 @@ def test_sharded_engines_match_single_engine(n, G, n3, monkeypatch):
         sc = np.array([engines[0].combine_scalars(np.ascontiguousarray(parts[:, s])) for s in range(nsteps)])
         assert np.max(np.abs(sc - ref) / np.abs(ref)) < 1e-11
         S = n // G
+        owned = []
         for g, e in enumerate(engines):
             assert e.shard_range() == (g * S, (g + 1) * S)
+            ids = e.particle_ids()
+            owned.append(ids)
+            assert e.migrations() == (2 if migrate else 0)
+            if not migrate:
+                assert np.array_equal(ids, np.arange(g * S, (g + 1) * S))
             st = e.get_state()
             for key in ("r", "ru", "v", "a"):
                 mine = np.stack(st[key])
-                want = np.stack(ref_state[key])[:, g * S:(g + 1) * S]
+                want = np.stack(ref_state[key])[:, ids]
                 scale = max(np.abs(want).max(), 1.0)
                 assert np.abs(mine - want).max() < 1e-9 * scale, (g, key)
+        assert np.array_equal(np.sort(np.concatenate(owned)), np.arange(n))     # every particle owned exactly once
+        if migrate:
+            # a rank's block is compact: its extent along the first split axis is about half the box (G >= 2)
+            x0 = np.stack(engines[0].get_state(("r",))["r"])[0]
+            assert x0.max() - x0.min() < 0.62 * p.box_length
+            # the GLOBAL arrays of set_state order keep working as input: a round trip of a and ru through ids
+            glob = {key: np.empty((3, n)) for key in ("ru", "a")}
+            for g, e in enumerate(engines):
+                st = e.get_state(("ru", "a"))
+                for key in glob:
+                    glob[key][:, owned[g]] = np.stack(st[key])
+            for g, e in enumerate(engines):
+                before = e.get_state(("ru", "a"))
+                e.set_unwrapped(*glob["ru"])
+                e.set_accel(*glob["a"])
+                after = e.get_state(("ru", "a"))
+                for key in glob:
+                    assert np.array_equal(np.stack(after[key]), np.stack(before[key])), (g, key)
         with pytest.raises(ljmd_amd.LjmdError):
             engines[0].allgather_positions()           # n_ranks > 1 without ljmd_comm_init
     finally:
@@ -258,9 +309,11 @@ def test_multi_device_handle_emulated_ranks(n, G, monkeypatch):
 def test_multi_device_handle_ownership_migration(n, G, monkeypatch):
     """A rank owns an index range, i.e. a fixed set of particles that diffuses out of its slab in a liquid; every
     LJMD_MULTI_MIGRATE_EVERY steps the multi-device handle deals the particles out again by position.
-    With a migration before every 20-step segment: the energy series and the final state -- in the CALLER's particle order,
-    unwrapped positions included -- against the same run without migration and against the single engine; snapshots and
-    set_unwrapped / set_accel round trips through the owner table; run-to-run bitwise."""
+    With a migration at set_state and before every 20-step segment: the energy series and the final state -- in the CALLER's
+    particle order, unwrapped positions included -- against the same run without migration and against the single engine;
+    set_unwrapped / set_accel round trips through the owner table; run-to-run bitwise.  The calls come in the production
+    driver's order (md_simulation_gpu.f90): collect, snapshot_begin, enqueue the next segment -- a migration is due right
+    there, with the snapshot in flight and, one segment later, with step records still pending -- snapshot_end."""
     monkeypatch.setenv("LJMD_N3_MIN_N", "1")
     p, r, v = synthetic.make_config(n, seed=9)
     segs, seg = 6, 20
@@ -272,12 +325,19 @@ def test_multi_device_handle_ownership_migration(n, G, monkeypatch):
             eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
             eng.compute_forces()
             rows, snap = [], None
+            eng.enqueue_steps(seg)
             for k in range(segs):
-                eng.enqueue_steps(seg)
-                if k == 3:
-                    eng.snapshot_begin()
+                if k == 4:
+                    eng.enqueue_steps(seg)             # ... with the records of segment 4 still waiting on the devices
+                    rows.append(np.stack(eng.collect_steps(2 * seg), axis=1))
+                    continue
+                if k == 5:
+                    continue
                 rows.append(np.stack(eng.collect_steps(seg), axis=1))
-                if k == 3:
+                if k == 2:
+                    eng.snapshot_begin()
+                eng.enqueue_steps(seg)                 # migration due, snapshot in flight
+                if k == 2:
                     snap = eng.snapshot_end()
             st = eng.get_state()
             n_mig = eng.migrations()
@@ -291,7 +351,7 @@ def test_multi_device_handle_ownership_migration(n, G, monkeypatch):
         return np.concatenate(rows), st, snap, n_mig, more
 
     sc_m, st_m, snap_m, n_mig, more_m = run(seg, [0] * G)
-    assert n_mig == segs - 1                                   # before every segment but the first
+    assert n_mig == segs                                       # at set_state and before every segment but the first
     sc_0, st_0, snap_0, n0, more_0 = run(0, [0] * G)
     assert n0 == 0
     sc_1, st_1, snap_1, _n1, more_1 = run(0, None)             # the single engine
@@ -366,6 +426,128 @@ def test_sharded_form_at_bench_size_eight_ranks_one_force_call():
     assert np.allclose(e8, e1, rtol=1e-12, atol=0), (e8, e1)
     assert np.abs(a8 - a1).max() <= 1e-12 * np.abs(a1).max()
     assert np.abs(a8.sum(axis=1)).max() <= 1e-9 * np.abs(a1).max()             # Newton 3 across ranks
+
+
+def test_config4_sharded_eight_ranks_n1048576(oracle):
+    """BASELINE config 4 in its defining form: N = 1 048 576 = 4 * 64^3, FCC sites in the reference's order
+    (md_initial_config_program.f90:144-178) + jitter, sharded over EIGHT ranks -- here eight rank engines on this box's one
+    card through the multi-device handle (peer-copy exchange; fpart[8] blocks of 131 072 particles, NG/2 ties at
+    NG = 4096, 3 MB per rank and step of positions).  One force call + 2 steps:
+      * accelerations against the CPU oracle's full-matrix rows (the reference's per-pair arithmetic) on 2048-row blocks
+        spread over the caller's index range, i.e. over the k-d blocks of all eight ranks: 1e-12 max|a|;
+      * the three scalars and the two steps' series against the ONE-rank engine: 1e-12 relative;
+      * Newton 3 across ranks: total force zero; the ranks really own blocks (8 migrated shards, one deal)."""
+    import ctypes
+    import os
+    n, G = 1048576, 8
+    p, r, v = synthetic.make_config(n, lattice="fcc")
+    with Engine(p) as one:
+        one.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e1 = one.compute_forces()
+        sc1 = np.stack(one.verlet_steps(2), axis=1)
+    with Engine(p, devices=[0] * G) as multi:
+        multi.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert multi.migrations() == 1                      # dealt by position at set_state
+        e8 = multi.compute_forces()
+        a8 = np.stack(multi.get_state(("a",))["a"])
+        sc8 = np.stack(multi.verlet_steps(2), axis=1)
+    assert np.allclose(e8, e1, rtol=1e-12, atol=0), (e8, e1)
+    assert np.max(np.abs(sc8 - sc1) / np.abs(sc1)) < 1e-12
+    amax = np.abs(a8).max()
+    assert np.abs(a8.sum(axis=1)).max() <= 1e-9 * amax * np.sqrt(n)
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    po = oracle.derive_params(p.n, p.box_length, p.dt, p.rc)
+    x, y, z = (np.ascontiguousarray(q) for q in r)
+    worst = 0.0
+    for i0 in range(3 * 2048, n, n // 6):                   # six blocks of 2048 rows across the FCC cell order
+        ax, ay, az, _e, _d, _dd = oracle.rows_raw(po, i0, i0 + 2048, x, y, z)
+        ao = 24.0 * np.stack([ax, ay, az])
+        worst = max(worst, np.abs(a8[:, i0:i0 + 2048] - ao).max() / amax)
+    print(f"config 4, 8 ranks: epot rel.diff vs one rank {abs(e8[0] - e1[0]) / abs(e1[0]):.2e}, accelerations vs oracle rows "
+          f"{worst:.2e} max|a| ({cores} oracle threads)")
+    assert worst <= 1e-12
+
+
+def test_bench_ladder_rehearsal_on_one_card(tmp_path):
+    """bench.py --gpus 2 on this one-GPU box with every rank on device 0 (LJMD_BENCH_SHARE_DEVICE=1): RCCL refuses two
+    ranks on one device, so the first two rungs of the launch ladder fail (for real, not by stand-ins) and the
+    peer-copy rung delivers the line -- watchdog, process-tree handling and the single-process worker end to end."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(LJMD_BENCH_SHARE_DEVICE="1")
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--particles", "32768", "--no-liquid"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len([ln for ln in out.stdout.splitlines() if ln.strip()]) == 1
+    cfg = lines[0]["config"]
+    assert cfg["launch_mode"] == "multi-copy" and "peer-to-peer" in cfg["exchange"]
+    assert [a["mode"] for a in cfg["ladder"]] == ["ranks-rccl", "multi-rccl", "multi-copy"]
+    assert [a["outcome"] for a in cfg["ladder"]][2] == "ok" and all(a["outcome"].startswith("exit") for a in cfg["ladder"][:2])
+    assert cfg["rccl_ranks_seen"] == 0 and len(cfg["pair_kernel_ms_per_rank"]) == 2
+    assert all(ms > 0 for ms in cfg["pair_kernel_ms_per_rank"] + cfg["position_exchange_ms_per_rank"] +
+               cfg["force_exchange_ms_per_rank"])
+    assert lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0 and lines[0]["energy_check"]["rel_drift"] < 1e-3
+
+
+@pytest.mark.parametrize("exchange", ["copy", "host"])
+def test_multi_device_handle_exchange_forms_are_bitwise_equal(exchange, monkeypatch):
+    """The three exchanges of the multi-device handle move the same bytes and add the force blocks in the same rank
+    order: peer copies (default on one card), pinned-host staging, and both with the exchanges on the engine streams
+    (LJMD_OVERLAP_EXCHANGE=0) give bit-identical trajectories; gather-kernel sizes (no force exchange) included."""
+    out = []
+    for n, env in ((16384, {"LJMD_N3_MIN_N": "1"}), (2048, {})):
+        p, r, v = synthetic.make_config(n, seed=17)
+        runs = []
+        for x, ov in (("copy", "1"), (exchange, "1"), (exchange, "0")):
+            for k, val in dict(env, LJMD_MULTI_EXCHANGE=x, LJMD_OVERLAP_EXCHANGE=ov).items():
+                monkeypatch.setenv(k, val)
+            with Engine(p, devices=[0, 0, 0, 0]) as eng:
+                eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+                e0 = eng.compute_forces()
+                sc = np.stack(eng.verlet_steps(45), axis=1)         # crosses re-sorts
+                runs.append((e0, sc, eng.get_state()))
+        for e0, sc, st in runs[1:]:
+            assert e0 == runs[0][0] and np.array_equal(sc, runs[0][1])
+            for key in ("r", "ru", "v", "a"):
+                assert np.array_equal(np.stack(st[key]), np.stack(runs[0][2][key])), key
+        out.append(runs[0][1])
+    assert all(np.all(np.isfinite(sc)) for sc in out)
+
+
+def test_multi_device_handle_rc_at_half_box_falls_back_to_the_generic_kernel():
+    """The reference accepts rc_over_L up to 0.5 and rejects only rc >= L/2 (md_types.f90:152).  Within 1e-9 of L/2 the
+    fast kernels' minimum image is not safe: a single engine takes the exact generic kernel, and a multi-rank run must do
+    the same on every rank (no Newton-3 force exchange allocated) instead of refusing to run."""
+    n = 4096
+    p0, r, v = synthetic.make_config(n, seed=4)
+    p = init_params(n, p0.box_length, p0.dt, 0.5 * p0.box_length * (1.0 - 1e-12))
+    with Engine(p) as one:
+        one.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert one.pair_kernel_name() == "pair_rows_generic_kernel"
+        e1 = one.compute_forces()
+        sc1 = np.stack(one.verlet_steps(5), axis=1)
+    with Engine(p, devices=[0, 0]) as two:
+        two.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        assert two.pair_kernel_name() == "pair_rows_generic_kernel"
+        e2 = two.compute_forces()
+        sc2 = np.stack(two.verlet_steps(5), axis=1)
+    assert np.allclose(e2, e1, rtol=1e-13, atol=0)
+    assert np.max(np.abs(sc2 - sc1) / np.abs(sc1)) < 1e-11
 
 
 def test_multi_device_handle_poisoned_after_failed_batch_and_recovers(monkeypatch):

@@ -1,15 +1,36 @@
-import os, sys, time
-sys.path.insert(0, '/root/repo')
-import ljmd_amd
-from ljmd_amd import Engine, synthetic
-for n in (65536, 262144):
+#!/usr/bin/env python3
+"""Cost of one ownership migration (ljmd_migrate: pack, all-gather of ru/v/a/ids, k-d deal of all n particles on every
+rank, select, re-sort of every shard, position exchange) with eight rank engines on ONE card (peer-copy exchange: every
+rank's sorts run one after the other here; on eight devices they run side by side).  Measurement tool."""
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import ljmd_amd  # noqa: E402,F401
+from ljmd_amd import Engine, synthetic  # noqa: E402
+
+G = int(os.environ.get("PROBE_G", "8"))
+for n in (65536, 262144, 1048576):
     p, r, v = synthetic.make_config(n)
-    os.environ["LJMD_MULTI_MIGRATE_EVERY"] = "10"
-    with Engine(p, devices=[0] * 8) as eng:
+    os.environ["LJMD_MULTI_MIGRATE_EVERY"] = "1000000"
+    with Engine(p, devices=[0] * G) as eng:
         eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
         eng.compute_forces()
-        eng.advance(10)            # steps_since_migration = 10 afterwards
+        eng.advance(10)
         eng.synchronize()
-        t0 = time.perf_counter(); eng.advance(1); eng.synchronize(); t1 = time.perf_counter()   # migration + 1 step
-        eng.advance(1); eng.synchronize(); t2 = time.perf_counter()                               # 1 step
-        print(f"n={n}: migration + 1 step {1e3*(t1-t0):.1f} ms, 1 step {1e3*(t2-t1):.1f} ms, migrations {eng.migrations()}", flush=True)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            eng.migrate()
+            eng.synchronize()
+            ts.append(time.perf_counter() - t0)
+            eng.advance(2)
+            eng.synchronize()
+        t0 = time.perf_counter()
+        eng.advance(5)
+        eng.synchronize()
+        step = (time.perf_counter() - t0) / 5
+        print(f"n={n} G={G} on one card: migration {1e3 * min(ts):.2f} ms (of 3: {', '.join('%.2f' % (1e3 * t) for t in ts)}), "
+              f"one step of all ranks {1e3 * step:.2f} ms, migrations {eng.migrations()}", flush=True)

@@ -23,9 +23,12 @@ for G in (1, 2, 4, 8):
         eng.verlet_steps(3)
         eng.synchronize()
         t0 = time.perf_counter()
-        e, k, d, dd = eng.verlet_steps(steps)
+        eng.enqueue_steps(steps)                     # returns when everything is enqueued: the host thread's share
+        host = time.perf_counter() - t0
+        e, k, d, dd = eng.collect_steps(steps)
         secs = time.perf_counter() - t0
     et = e[-1] + k[-1]
     ref = et if ref is None else ref
-    print(f"G = {G}: {1e3 * secs / steps:8.3f} ms per step for the whole system on one card ({steps / secs:6.2f} steps/s), "
+    print(f"G = {G}: host enqueue {1e3 * host / steps:6.3f} ms per step ({1e3 * host / steps / G:6.3f} per rank), "
+          f"{1e3 * secs / steps:8.3f} ms per step for the whole system on one card ({steps / secs:6.2f} steps/s), "
           f"epot(t=0) = {e0[0]:.12e}, Etot after {steps + 3} steps rel. to G = 1: {abs(et - ref) / abs(ref):.1e}", flush=True)
