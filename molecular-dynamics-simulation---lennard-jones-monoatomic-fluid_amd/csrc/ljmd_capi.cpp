@@ -76,6 +76,7 @@ N3Args n3_args(ljmd_t *h)
     a.mask = h->d_mask;
     a.bbox = h->d_bbox;
     a.desc = h->d_desc;
+    a.desc2 = h->d_desc2;
     a.slab_i = h->d_slab;
     a.slab_j = h->d_slab_j;
     a.flag_j = h->d_flag_j;
@@ -276,7 +277,7 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         h->boxes_valid = false;                    // good for this evaluation only
         if (h->use_n3)      // tile-pair test + pass descriptors of the Newton-3 kernels in one launch (mixed mode: NEAR and FAR)
             LJMD_HIP(h, launch_tile_class(ga, h->invL, h->rc2, h->S, h->NGo, h->d_desc,
-                                          h->mode == LJMD_PRECISION_FP32_FORCE ? h->d_desc_far : nullptr, h->stream));
+                                          h->mode == LJMD_PRECISION_FP32_FORCE ? h->d_desc_far : nullptr, h->d_desc2, h->stream));
         else                // the gather kernel reads the bit mask
             LJMD_HIP(h, launch_tile_mask(ga, h->stream));
         if (q) LJMD_HIP(h, hipEventRecord(q->e[2], h->stream));
@@ -522,7 +523,7 @@ void release(ljmd_t *h)
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv, h->d_fall,
                    h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket,
-                   h->d_desc, h->d_desc_far, h->d_pos_tc, h->d_gid0, h->d_mig, h->d_mig_idx, h->d_mig_idx2, h->d_mig_keys,
+                   h->d_desc, h->d_desc_far, h->d_desc2, h->d_pos_tc, h->d_gid0, h->d_mig, h->d_mig_idx, h->d_mig_idx2, h->d_mig_keys,
                    h->d_mig_keys2, h->d_mig_offsets, h->d_mig_cub};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -932,6 +933,9 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
             LJMD_HIP(h, hipMalloc(&h->d_flag_j, n_blk));
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, n_blk, h->stream));
             LJMD_HIP(h, hipMalloc(&h->d_desc, (size_t)h->NGo * h->T * sizeof(unsigned)));
+            // cluster passes (ljmd_kernels.hip: n3_cluster_pass): 4-tile row groups, one wave per workgroup
+            if (h->rt == kRowTiles && h->wg_waves == 1 && env_int("LJMD_N3_CLUSTERS", 1) != 0)
+                LJMD_HIP(h, hipMalloc(&h->d_desc2, (size_t)h->NGo * h->T * 8 * sizeof(float)));
             LJMD_HIP(h, hipMalloc(&h->d_pos_tc, P3 * h->G));
         }
         if (mixed) {

@@ -104,6 +104,7 @@ struct ljmd {
     double *d_pos_tc = nullptr;   // [G][3][P] tile-coherent copy of d_pos for the Newton-3 kernels (tile_boxes_kernel)
     unsigned *d_desc = nullptr;   // [NGo][T] pass descriptors of the Newton-3 kernel (tile_class_kernel)
     unsigned *d_desc_far = nullptr;   // same for the fp32 far kernel of the mixed mode (from mask_far)
+    float *d_desc2 = nullptr;     // [NGo][T][8] direction + thresholds of the cluster passes (LJMD_N3_CLUSTERS, default on)
     // sorting scratch
     unsigned *d_keys = nullptr, *d_keys2 = nullptr;
     int *d_idx = nullptr, *d_idx2 = nullptr, *d_perm = nullptr, *d_perm2 = nullptr;

@@ -54,6 +54,7 @@ struct N3Args {
     const uint64_t *mask;   // [TB rows][W] tile-pair mask of the owned row tiles
     const double *bbox;     // [T][kBoxStride] exact tile bounding boxes (fp32 far kernel: image classification)
     const unsigned *desc;   // [NGo][T] pass descriptors of tile_class_kernel (row-tile mask bits, loop variant, images)
+    const float *desc2;     // [NGo][T][8] cluster passes: direction n (3), thresholds of the RT row tiles (4), pad; or NULL
     double *slab_i;         // [nchunk][3][P] partial accelerations of the owned rows (row side)
     double *slab_j;         // [ceil(NGo/WG)][Q][3][64] column-side partial accelerations: one block per (workgroup of WG
                             // consecutive row groups, column tile), Q = (Dmax + WG) * RT column tiles per workgroup
@@ -156,7 +157,7 @@ hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc,
-                             unsigned *desc_far, hipStream_t s);
+                             unsigned *desc_far, float *desc2 /* cluster passes, or NULL: none */, hipStream_t s);
 
 // ljmd_sort.hip
 size_t sort_temp_bytes(int count);

@@ -16,7 +16,7 @@ from ljmd_amd import Engine, synthetic, _lib  # noqa: E402
 n = int(os.environ.get("STATS_N", "262144"))
 p, r, v = synthetic.make_config(n)
 lib = _lib.load()
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 80)()
 names = {8: "no image", 16: "common image, x only", 17: "common image, y only", 18: "common image, z only",
          0: "common image, several axes", 24: "x general, others no image", 25: "y general, others no image", 26: "z general, others no image", 1: "x general", 2: "y general", 4: "z general", 7: "all general"}
 with Engine(p) as eng:
@@ -33,8 +33,15 @@ with Engine(p) as eng:
         by_rows = [buf[56 + k] for k in range(5)]
         tot = sum(buf[k] for k in range(56))
         pairs_all = n * (n - 1) / 2
-        print(f"== {label}: {tot} (row tile, column tile) passes = {tot * 4096 / pairs_all:.3f} of all unordered pairs "
+        clu = [buf[64 + k] for k in range(5)]                   # cluster passes: (cluster, active row tiles) counts
+        clu_rows = sum(k * clu[k] for k in range(5))
+        print(f"== {label}: {tot} (row tile, column tile) passes in the 64-step loops + {clu_rows} (row tile, 16-cluster) "
+              f"passes = {(tot * 4096 + clu_rows * 1024) / pairs_all:.3f} of all unordered pairs "
               f"(diagonal-tile passes are not counted)")
+        if sum(clu):
+            print(f"  cluster passes: {sum(clu) // 4} column tiles; clusters by active row tiles (0..4): "
+                  + ", ".join(f"{k}: {100.0 * clu[k] / sum(clu):.1f} %" for k in range(5))
+                  + f"; pair evaluations in clusters: {100.0 * clu_rows * 1024 / (tot * 4096 + clu_rows * 1024):.1f} % of all")
         rows_tot = sum(k * by_rows[k] for k in range(5))
         if rows_tot:
             print("  column-tile passes by number of active row tiles (1..4): "
