@@ -308,6 +308,47 @@ class MultiHandleSim:
         return self.collect(nsteps)
 
 
+def committed_parity_summary():
+    """newest profiles/rNN_mixed_precision_parity_vs_oracle.json (written by tests/test_gpu_parity.py on the GPU box)"""
+    hits = sorted((ROOT / "profiles").glob("r[0-9][0-9]_mixed_precision_parity_vs_oracle.json"))
+    if not hits:
+        return None
+    return dict(json.loads(hits[-1].read_text()), source=f"profiles/{hits[-1].name}")
+
+
+def mixed_precision_leg(args, p, r, v, etot_fp64, barrier_extra=None) -> dict:
+    """K timed steps of the mixed-precision engine from the start the fp64 headline used (warm-up included), on device 0."""
+    from ljmd_amd import Engine
+    from ljmd_amd import _lib as _abi
+    with Engine(p, device=0, precision_mode=_abi.PRECISION_FP32_FORCE) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        eng.compute_forces()
+        if args.warmup > 0:
+            eng.verlet_steps(args.warmup)
+        eng.profile_enable(True)
+        eng.synchronize()
+        if barrier_extra:
+            barrier_extra.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.enqueue_steps(args.steps)
+        eng.synchronize()
+        if barrier_extra:
+            barrier_extra.cuda.synchronize()
+        el = time.perf_counter() - t0
+        prof = eng.profile_read()
+        e, k, _d, _dd = eng.collect_steps(args.steps)
+    et = e + k
+    out = {"metric": f"md_steps_per_sec_n{p.n}_mixed_fp32_far_pairs", "value": args.steps / el, "unit": "steps/s",
+           "ms_per_step": 1e3 * el / args.steps, "pair_kernels_ms_avg": prof["pair_ms"],
+           "dtype": "f32 far pairs (box distance > 5 sigma) / f64 near pairs, accumulation and integrator",
+           "etot_max_rel_dev_from_fp64_series": float(np.max(np.abs(et - etot_fp64) / np.abs(etot_fp64))),
+           "note": "same K steps from the same start as the fp64 headline; not the headline"}
+    parity = committed_parity_summary()
+    if parity:
+        out["parity_vs_oracle"] = parity
+    return out
+
+
 def kernel_source_sha16() -> str:
     """identifies the kernel sources a committed PMC summary was collected with (tools/pmc_summary.py stores the same)"""
     hsh = hashlib.sha256()
@@ -520,11 +561,11 @@ def measure(args) -> None:
             # two pair kernels (fp64 near, fp32 far) share the timed interval: no single-peak roofline applies
             line["roofline"].update({"bound": "fp64-valu (near pairs) + fp32-valu (far pairs)", "frac": None,
                                      "note": "achieved = reference-algorithm fp64 flop / time of both pair kernels"})
-            parity = sorted((ROOT / "profiles").glob("r[0-9][0-9]_mixed_precision_parity_vs_oracle.json"))
+            parity = committed_parity_summary()
             if parity:
                 # config 5's accuracy beside its rate: measured deviations of ONE force call of this workload from
                 # the CPU oracle over all ordered pairs (tests/test_gpu_parity.py writes the summary)
-                line["parity_vs_oracle"] = dict(json.loads(parity[-1].read_text()), source=f"profiles/{parity[-1].name}")
+                line["parity_vs_oracle"] = parity
         # the HBM-bound kernel of the step, K1 (drift + wrap + half-kick + unwrapped update): 168 N algorithmic
         # bytes per launch / its shortest HIP-event interval (= K1 alone; steps that re-sort are longer)
         if prof.get("drift_ms_min", 0.0) > 0.0 and n_ranks == 1:
@@ -611,6 +652,14 @@ def measure(args) -> None:
                                                         "rocprof_frac": gbps / HBM_PEAK_GBPS,
                                                         "rocprof_source": f"profiles/{stats.name}"})
                     break
+        # BASELINE config 5 beside the fp64 headline, in the same run: the same workload with the fp32 far-pair kernel
+        # (LJMD_PRECISION_FP32_FORCE), K steps timed the same way from the same start, and what it costs in accuracy --
+        # the energy series against this run's fp64 one, and the committed one-force-call parity against the CPU oracle
+        if n_ranks == 1 and args.mode == "fp64" and not args.no_liquid and n >= 16384:
+            try:
+                line["config5_mixed_precision"] = mixed_precision_leg(args, p, r, v, etot, barrier_extra=torch_gpu and torch)
+            except Exception as exc:  # noqa: BLE001 - a secondary figure, never a reason to lose the bench line
+                line["config5_mixed_precision"] = {"value": None, "error": str(exc)}
         if n_ranks == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

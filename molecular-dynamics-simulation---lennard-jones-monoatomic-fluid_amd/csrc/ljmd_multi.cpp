@@ -22,10 +22,28 @@
 // in rank order (combine_one), exactly as the multi-process path does.
 #include "ljmd_multi.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <thread>
+
 using namespace ljmdk;
 using namespace ljmdh;
 
 enum Exchange { kRccl, kCopy, kHost };
+
+// one host thread per rank for the step loop (ljmd_multi.cpp: team_*)
+struct StepTeam {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    unsigned seq = 0;                             // command counter: a new value = a new batch of steps
+    bool quit = false, sampled = false;
+    int nsteps = 0, done = 0;
+    std::vector<int> rc;
+    std::atomic<int> arrived{0}, generation{0};   // spinning barrier between the phases of a step
+    std::atomic<bool> broken{false};              // a rank failed: nobody waits for it any more
+};
 
 struct ljmd_multi {
     int G = 0;
@@ -50,6 +68,7 @@ struct ljmd_multi {
                                                   // through it, whatever migrations happen before ljmd_snapshot_end
     int migrate_every = 0, steps_since_migration = 0, migrations = 0;
     std::vector<double> stage[12];                // engine-order staging of r, ru, v, a (x, y, z each)
+    std::unique_ptr<StepTeam> team;               // LJMD_MULTI_THREADS (default on for G > 1)
 };
 
 namespace ljmdm {
@@ -88,200 +107,336 @@ int nccl_failed(ljmd_t *h, const char *what, ncclResult_t r)
     return fail(h, LJMD_ERR_HIP, "multi-device %s failed: %s", what, ncclGetErrorString(r));
 }
 
-// Position exchange: every rank's own block (3P doubles, final for this step) into every other rank's exchange buffer.
-// Issued on the communication streams xs[g]; nothing on an engine stream waits for it until await_positions().
-// q: the ranks' event sets of this step (NULL entries: not profiled).
-int exchange_positions(ljmd_t *h, const std::vector<EventSet *> &q)
+bool exchanges(const ljmd_multi *m) { return m->G > 1 || m->eng[0]->force_collectives; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two exchanges, rank by rank.  Every function below is called with rank g's device current and reports errors on
+// rank g's own engine handle (so that the ranks can be driven by one host thread each: StepTeam); the caller turns a
+// failure into the parent's (child_failed).  An exchange = prepare (what the OWNER of a block does), collect (what the
+// RECEIVER does: the collective call / the pulls), finish.  With peer copies or host staging a rank's collect may only
+// be issued after EVERY rank's prepare (hipStreamWaitEvent captures the event's latest record at the time of the call):
+// the single-thread driver runs the phases as loops over the ranks, the threaded one puts a host barrier between them;
+// RCCL needs neither (the collective is its own synchronisation), but from one thread its calls must be grouped.
+// ---------------------------------------------------------------------------------------------------------------------
+
+// positions: "rank g's block is final" + (host staging) its copy in pinned memory
+int pos_prepare(ljmd_multi *m, int g, EventSet *q)
+{
+    ljmd_t *e = m->eng[g];
+    LJMD_HIP(e, hipEventRecord(m->ev_pos[g], e->stream));
+    // the rank's own event first: behind it the rank's previous pair kernel has finished reading the blocks that are
+    // about to be overwritten, and the exchange interval (events 5 -> 6) starts when THIS rank could start
+    LJMD_HIP(e, hipStreamWaitEvent(m->xs[g], m->ev_pos[g], 0));
+    if (q) LJMD_HIP(e, hipEventRecord(q->e[5], m->xs[g]));
+    if (m->xmode == kHost) {
+        LJMD_HIP(e, hipMemcpyAsync(m->h_xpos[g], own_block(e), 3 * (size_t)e->P * sizeof(double), hipMemcpyDeviceToHost,
+                                   m->xs[g]));
+        LJMD_HIP(e, hipEventRecord(m->ev_hpos[g], m->xs[g]));
+    }
+    return LJMD_OK;
+}
+
+// positions: every other rank's block into rank d's exchange buffer
+int pos_collect(ljmd_multi *m, int d)
+{
+    ljmd_t *dst = m->eng[d];
+    const size_t blk = 3 * (size_t)dst->P;
+    if (m->xmode == kRccl) {
+        const ncclResult_t r = ncclAllGather(own_block(dst), dst->d_pos, blk, ncclDouble, m->comm[d], m->xs[d]);
+        if (r != ncclSuccess) return fail(dst, LJMD_ERR_HIP, "all-gather failed: %s", ncclGetErrorString(r));
+        return LJMD_OK;
+    }
+    for (int g = 0; g < m->G; ++g) {
+        if (g == d) continue;
+        if (m->xmode == kHost) {
+            LJMD_HIP(dst, hipStreamWaitEvent(m->xs[d], m->ev_hpos[g], 0));
+            LJMD_HIP(dst, hipMemcpyAsync(dst->d_pos + (size_t)g * blk, m->h_xpos[g], blk * sizeof(double),
+                                         hipMemcpyHostToDevice, m->xs[d]));
+        } else {
+            LJMD_HIP(dst, hipStreamWaitEvent(m->xs[d], m->ev_pos[g], 0));
+            LJMD_HIP(dst, hipMemcpyAsync(dst->d_pos + (size_t)g * blk, own_block(m->eng[g]), blk * sizeof(double),
+                                         hipMemcpyDeviceToDevice, m->xs[d]));
+        }
+    }
+    return LJMD_OK;
+}
+
+int pos_finish(ljmd_multi *m, int g, EventSet *q)
+{
+    ljmd_t *e = m->eng[g];
+    if (q) {
+        LJMD_HIP(e, hipEventRecord(q->e[6], m->xs[g]));
+        q->has_pos_x = true;
+    }
+    LJMD_HIP(e, hipEventRecord(m->ev_got[g], m->xs[g]));
+    return LJMD_OK;
+}
+
+// the engine stream resumes behind the position exchange
+int pos_await(ljmd_multi *m, int g)
+{
+    LJMD_HIP(m->eng[g], hipStreamWaitEvent(m->eng[g]->stream, m->ev_got[g], 0));
+    return LJMD_OK;
+}
+
+// forces (Newton-3): rank d's frecv = sum over the ranks g of block d of rank g's fpart, in rank order
+int force_prepare(ljmd_multi *m, int g, EventSet *q)
+{
+    ljmd_t *e = m->eng[g];
+    LJMD_HIP(e, hipEventRecord(m->ev_force[g], e->stream));
+    LJMD_HIP(e, hipStreamWaitEvent(m->xs[g], m->ev_force[g], 0));
+    if (q) LJMD_HIP(e, hipEventRecord(q->e[7], m->xs[g]));
+    if (m->xmode == kHost) {
+        LJMD_HIP(e, hipMemcpyAsync(m->h_xforce[g], e->d_fpart, (size_t)m->G * 3 * e->P * sizeof(double), hipMemcpyDeviceToHost,
+                                   m->xs[g]));
+        LJMD_HIP(e, hipEventRecord(m->ev_hforce[g], m->xs[g]));
+    }
+    return LJMD_OK;
+}
+
+int force_collect(ljmd_multi *m, int d)
+{
+    ljmd_t *dst = m->eng[d];
+    const size_t blk = 3 * (size_t)dst->P;
+    if (m->xmode == kRccl) {
+        const ncclResult_t r = ncclReduceScatter(dst->d_fpart, dst->d_frecv, blk, ncclDouble, ncclSum, m->comm[d], m->xs[d]);
+        if (r != ncclSuccess) return fail(dst, LJMD_ERR_HIP, "reduce-scatter failed: %s", ncclGetErrorString(r));
+        return LJMD_OK;
+    }
+    for (int g = 0; g < m->G; ++g) {
+        if (m->xmode == kHost) {
+            LJMD_HIP(dst, hipStreamWaitEvent(m->xs[d], m->ev_hforce[g], 0));
+            LJMD_HIP(dst, hipMemcpyAsync(dst->d_fall + (size_t)g * blk, m->h_xforce[g] + (size_t)d * blk, blk * sizeof(double),
+                                         hipMemcpyHostToDevice, m->xs[d]));
+        } else {
+            if (g != d) LJMD_HIP(dst, hipStreamWaitEvent(m->xs[d], m->ev_force[g], 0));
+            LJMD_HIP(dst, hipMemcpyAsync(dst->d_fall + (size_t)g * blk, m->eng[g]->d_fpart + (size_t)d * blk,
+                                         blk * sizeof(double), hipMemcpyDeviceToDevice, m->xs[d]));
+        }
+    }
+    LJMD_HIP(dst, launch_sum_blocks(dst->d_fall, dst->d_frecv, m->G, (int)blk, m->xs[d]));   // rank order
+    return LJMD_OK;
+}
+
+int force_finish(ljmd_multi *m, int g, EventSet *q)
+{
+    ljmd_t *e = m->eng[g];
+    if (q) {
+        LJMD_HIP(e, hipEventRecord(q->e[8], m->xs[g]));
+        q->has_force_x = true;
+    }
+    LJMD_HIP(e, hipEventRecord(m->ev_fgot[g], m->xs[g]));
+    LJMD_HIP(e, hipStreamWaitEvent(e->stream, m->ev_fgot[g], 0));
+    return LJMD_OK;
+}
+
+// ---- one MD step of rank g in three pieces; the exchanges' collect phases go between them --------------------------
+struct RankStep {
+    EventSet *q = nullptr;
+    bool split = false;
+};
+
+// Without a force exchange (gather kernels: small systems, LJMD_N3=0) nothing orders a rank's next drift -- which
+// overwrites its position block -- behind the OTHER ranks' pulls of that block in the previous step: with Newton-3 the
+// kick waits for everybody's forces, which closes the hazard by itself.
+bool needs_pull_guard(const ljmd_multi *m) { return m->G > 1 && m->xmode != kRccl && !needs_force_exchange(m->eng[0]); }
+
+int step_a(ljmd_multi *m, int g, RankStep &st)
+{
+    ljmd_t *e = m->eng[g];
+    if (needs_pull_guard(m))
+        for (int d = 0; d < m->G; ++d)
+            if (d != g) LJMD_HIP(e, hipStreamWaitEvent(e->stream, m->ev_got[d], 0));
+    // K1 in two halves: the positions (verlet.f90:58-63 + the unwrapped update) are final first, their exchange starts
+    // on the communication stream and the velocity half-kick (:72-74) runs beside it
+    st.q = next_events(e);
+    st.split = false;
+    if (m->overlap)
+        LJMD_TRY(enqueue_drift_positions(e, st.q, &st.split));     // (a re-sort step has already run all of K1)
+    else
+        LJMD_TRY(enqueue_drift(e, st.q));
+    return exchanges(m) ? pos_prepare(m, g, st.q) : LJMD_OK;
+}
+
+int step_b(ljmd_multi *m, int g, RankStep &st)
+{
+    ljmd_t *e = m->eng[g];
+    if (exchanges(m)) LJMD_TRY(pos_finish(m, g, st.q));
+    if (st.split) LJMD_TRY(enqueue_drift_velocities(e));
+    if (exchanges(m)) LJMD_TRY(pos_await(m, g));
+    LJMD_TRY(enqueue_pair_forces(e, st.q));
+    return needs_force_exchange(e) ? force_prepare(m, g, st.q) : LJMD_OK;
+}
+
+int step_c(ljmd_multi *m, int g, RankStep &st, bool kick)
+{
+    ljmd_t *e = m->eng[g];
+    if (needs_force_exchange(e)) LJMD_TRY(force_finish(m, g, st.q));
+    return enqueue_kick(e, kick, st.q);
+}
+
+// ---- the single-thread driver: every phase as a loop over the ranks ----------------------------------------------------
+#define LJMD_RANKS(h, m, expr)                                        \
+    for (int g = 0; g < (m)->G; ++g) {                                \
+        LJMD_HIP((h), hipSetDevice((m)->dev[g]));                     \
+        LJMD_CHILD((h), (m)->eng[g], (expr));                         \
+    }
+
+int collect_all(ljmd_t *h, bool forces)
 {
     ljmd_multi *m = h->multi;
-    const int G = m->G;
-    if (G == 1 && !m->eng[0]->force_collectives) return LJMD_OK;
-    for (int g = 0; g < G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        LJMD_HIP(h, hipEventRecord(m->ev_pos[g], m->eng[g]->stream));
-        // the rank's own event first: behind it the rank's previous pair kernel has finished reading the blocks that are
-        // about to be overwritten, and the exchange interval (events 5 -> 6) starts when THIS rank could start
-        LJMD_HIP(h, hipStreamWaitEvent(m->xs[g], m->ev_pos[g], 0));
-        if (q[g]) LJMD_HIP(h, hipEventRecord(q[g]->e[5], m->xs[g]));
+    ncclResult_t r = m->xmode == kRccl ? ncclGroupStart() : ncclSuccess;
+    if (r != ncclSuccess) return nccl_failed(h, "group start", r);
+    int rc_ = LJMD_OK;
+    for (int g = 0; g < m->G && rc_ == LJMD_OK; ++g) {
+        if (hipSetDevice(m->dev[g]) != hipSuccess) rc_ = fail(h, LJMD_ERR_HIP, "hipSetDevice(%d) failed", m->dev[g]);
+        if (rc_ == LJMD_OK) {
+            const int rg = forces ? force_collect(m, g) : pos_collect(m, g);
+            if (rg != LJMD_OK) rc_ = child_failed(h, m->eng[g], rg);
+        }
     }
     if (m->xmode == kRccl) {
-        ncclResult_t r = ncclGroupStart();
-        for (int g = 0; g < G && r == ncclSuccess; ++g) {
-            ljmd_t *e = m->eng[g];
-            r = ncclAllGather(own_block(e), e->d_pos, 3 * (size_t)e->P, ncclDouble, m->comm[g], m->xs[g]);
-        }
-        const ncclResult_t end = ncclGroupEnd();
-        if (r == ncclSuccess) r = end;
-        if (r != ncclSuccess) return nccl_failed(h, "all-gather", r);
-    } else {
-        if (m->xmode == kHost)
-            for (int g = 0; g < G; ++g) {
-                LJMD_HIP(h, hipSetDevice(m->dev[g]));
-                LJMD_HIP(h, hipMemcpyAsync(m->h_xpos[g], own_block(m->eng[g]), 3 * (size_t)m->eng[g]->P * sizeof(double),
-                                           hipMemcpyDeviceToHost, m->xs[g]));
-                LJMD_HIP(h, hipEventRecord(m->ev_hpos[g], m->xs[g]));
-            }
-        for (int d = 0; d < G; ++d) {
-            ljmd_t *dst = m->eng[d];
-            LJMD_HIP(h, hipSetDevice(m->dev[d]));
-            const size_t blk = 3 * (size_t)dst->P;
-            for (int g = 0; g < G; ++g) {
-                if (g == d) continue;
-                if (m->xmode == kHost) {
-                    LJMD_HIP(h, hipStreamWaitEvent(m->xs[d], m->ev_hpos[g], 0));
-                    LJMD_HIP(h, hipMemcpyAsync(dst->d_pos + (size_t)g * blk, m->h_xpos[g], blk * sizeof(double),
-                                               hipMemcpyHostToDevice, m->xs[d]));
-                } else {
-                    LJMD_HIP(h, hipStreamWaitEvent(m->xs[d], m->ev_pos[g], 0));
-                    LJMD_HIP(h, hipMemcpyAsync(dst->d_pos + (size_t)g * blk, own_block(m->eng[g]), blk * sizeof(double),
-                                               hipMemcpyDeviceToDevice, m->xs[d]));
-                }
-            }
-        }
+        r = ncclGroupEnd();
+        if (rc_ == LJMD_OK && r != ncclSuccess) rc_ = nccl_failed(h, forces ? "reduce-scatter" : "all-gather", r);
     }
-    for (int g = 0; g < G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        if (q[g]) {
-            LJMD_HIP(h, hipEventRecord(q[g]->e[6], m->xs[g]));
-            q[g]->has_pos_x = true;
-        }
-        LJMD_HIP(h, hipEventRecord(m->ev_got[g], m->xs[g]));
-    }
-    return LJMD_OK;
+    return rc_;
 }
 
-// the engine streams resume behind the position exchange
-int await_positions(ljmd_t *h)
-{
-    ljmd_multi *m = h->multi;
-    if (m->G == 1 && !m->eng[0]->force_collectives) return LJMD_OK;
-    for (int g = 0; g < m->G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        LJMD_HIP(h, hipStreamWaitEvent(m->eng[g]->stream, m->ev_got[g], 0));
-    }
-    return LJMD_OK;
-}
-
+// position exchange outside a step (after set_state / a migration): issued and awaited
 int exchange_positions_now(ljmd_t *h)
 {
-    const std::vector<EventSet *> none(h->multi->G, nullptr);
-    LJMD_TRY(exchange_positions(h, none));
-    return await_positions(h);
-}
-
-// Force exchange (Newton-3): rank d's frecv = sum over the ranks g of block d of rank g's fpart, in rank order; the
-// engine streams wait for it (the kick kernel reads frecv).
-int exchange_forces(ljmd_t *h, const std::vector<EventSet *> &q)
-{
     ljmd_multi *m = h->multi;
-    const int G = m->G;
-    if (!needs_force_exchange(m->eng[0])) return LJMD_OK;     // gather kernels: every rank already has its rows
-    for (int g = 0; g < G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        LJMD_HIP(h, hipEventRecord(m->ev_force[g], m->eng[g]->stream));
-        LJMD_HIP(h, hipStreamWaitEvent(m->xs[g], m->ev_force[g], 0));
-        if (q[g]) LJMD_HIP(h, hipEventRecord(q[g]->e[7], m->xs[g]));
-    }
-    if (m->xmode == kRccl) {
-        ncclResult_t r = ncclGroupStart();
-        for (int g = 0; g < G && r == ncclSuccess; ++g) {
-            ljmd_t *e = m->eng[g];
-            r = ncclReduceScatter(e->d_fpart, e->d_frecv, 3 * (size_t)e->P, ncclDouble, ncclSum, m->comm[g], m->xs[g]);
-        }
-        const ncclResult_t end = ncclGroupEnd();
-        if (r == ncclSuccess) r = end;
-        if (r != ncclSuccess) return nccl_failed(h, "reduce-scatter", r);
-    } else {
-        if (m->xmode == kHost)
-            for (int g = 0; g < G; ++g) {
-                LJMD_HIP(h, hipSetDevice(m->dev[g]));
-                LJMD_HIP(h, hipMemcpyAsync(m->h_xforce[g], m->eng[g]->d_fpart, (size_t)G * 3 * m->eng[g]->P * sizeof(double),
-                                           hipMemcpyDeviceToHost, m->xs[g]));
-                LJMD_HIP(h, hipEventRecord(m->ev_hforce[g], m->xs[g]));
-            }
-        for (int d = 0; d < G; ++d) {
-            ljmd_t *dst = m->eng[d];
-            LJMD_HIP(h, hipSetDevice(m->dev[d]));
-            const size_t blk = 3 * (size_t)dst->P;
-            for (int g = 0; g < G; ++g) {
-                if (m->xmode == kHost) {
-                    LJMD_HIP(h, hipStreamWaitEvent(m->xs[d], m->ev_hforce[g], 0));
-                    LJMD_HIP(h, hipMemcpyAsync(dst->d_fall + (size_t)g * blk, m->h_xforce[g] + (size_t)d * blk,
-                                               blk * sizeof(double), hipMemcpyHostToDevice, m->xs[d]));
-                } else {
-                    if (g != d) LJMD_HIP(h, hipStreamWaitEvent(m->xs[d], m->ev_force[g], 0));
-                    LJMD_HIP(h, hipMemcpyAsync(dst->d_fall + (size_t)g * blk, m->eng[g]->d_fpart + (size_t)d * blk,
-                                               blk * sizeof(double), hipMemcpyDeviceToDevice, m->xs[d]));
-                }
-            }
-            LJMD_HIP(h, launch_sum_blocks(dst->d_fall, dst->d_frecv, G, (int)blk, m->xs[d]));   // rank order
-        }
-    }
-    for (int g = 0; g < G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        if (q[g]) {
-            LJMD_HIP(h, hipEventRecord(q[g]->e[8], m->xs[g]));
-            q[g]->has_force_x = true;
-        }
-        LJMD_HIP(h, hipEventRecord(m->ev_fgot[g], m->xs[g]));
-        LJMD_HIP(h, hipStreamWaitEvent(m->eng[g]->stream, m->ev_fgot[g], 0));
-    }
+    if (!exchanges(m)) return LJMD_OK;
+    LJMD_RANKS(h, m, pos_prepare(m, g, nullptr));
+    LJMD_TRY(collect_all(h, false));
+    LJMD_RANKS(h, m, pos_finish(m, g, nullptr));
+    LJMD_RANKS(h, m, pos_await(m, g));
     return LJMD_OK;
 }
 
 // forces of all ranks on the positions in the exchange buffers (already exchanged) + optional second half-kick
-int enqueue_forces_all(ljmd_t *h, bool kick, const std::vector<EventSet *> &q)
+int enqueue_forces_all(ljmd_t *h, bool kick)
 {
     ljmd_multi *m = h->multi;
-    for (int g = 0; g < m->G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        LJMD_CHILD(h, m->eng[g], enqueue_pair_forces(m->eng[g], q[g]));
+    const bool fx = needs_force_exchange(m->eng[0]);
+    LJMD_RANKS(h, m, enqueue_pair_forces(m->eng[g], nullptr));
+    if (fx) {
+        LJMD_RANKS(h, m, force_prepare(m, g, nullptr));
+        LJMD_TRY(collect_all(h, true));
+        LJMD_RANKS(h, m, force_finish(m, g, nullptr));
     }
-    LJMD_TRY(exchange_forces(h, q));
-    for (int g = 0; g < m->G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        LJMD_CHILD(h, m->eng[g], enqueue_kick(m->eng[g], kick, q[g]));
-    }
+    LJMD_RANKS(h, m, enqueue_kick(m->eng[g], kick, nullptr));
     return LJMD_OK;
 }
 
 int enqueue_one_step(ljmd_t *h)
 {
     ljmd_multi *m = h->multi;
-    const int G = m->G;
-    std::vector<EventSet *> q(G, nullptr);
-    if (G > 1 && m->xmode != kRccl && !needs_force_exchange(m->eng[0])) {
-        // Without a force exchange (gather kernels: small systems, LJMD_N3=0) nothing orders a rank's next drift -- which
-        // overwrites its position block -- behind the OTHER ranks' pulls of that block in the previous step: with
-        // Newton-3 the kick waits for everybody's forces, which closes the hazard by itself.
-        for (int g = 0; g < G; ++g) {
-            LJMD_HIP(h, hipSetDevice(m->dev[g]));
-            for (int d = 0; d < G; ++d)
-                if (d != g) LJMD_HIP(h, hipStreamWaitEvent(m->eng[g]->stream, m->ev_got[d], 0));
+    std::vector<RankStep> st(m->G);
+    LJMD_RANKS(h, m, step_a(m, g, st[g]));
+    if (exchanges(m)) LJMD_TRY(collect_all(h, false));
+    LJMD_RANKS(h, m, step_b(m, g, st[g]));
+    if (needs_force_exchange(m->eng[0])) LJMD_TRY(collect_all(h, true));
+    LJMD_RANKS(h, m, step_c(m, g, st[g], true));
+    return LJMD_OK;
+}
+
+// ---- the threaded driver: one host thread per rank (StepTeam) ------------------------------------------------------------
+// One thread issuing every launch of G devices costs G x (launches + event calls) of host time per step: 1.36 ms at G = 8,
+// n = 262144 with peer copies, 46 % of a rank's 2.97 ms step (profiles/r03_multi_handle_host_enqueue_one_thread.txt),
+// and more than a whole step for smaller systems.  The team's threads live as long as the handle; a batch of steps is one
+// command, inside which thread g issues rank g's launches and ITS side of both exchanges.  Host barriers (spinning: a
+// few microseconds) stand where a rank's pulls must not be issued before the other ranks' "block ready" events are
+// recorded; with RCCL there is none -- every thread calls its own communicator, the one-device-per-thread usage.
+bool team_barrier(ljmd_multi *m)
+{
+    StepTeam &t = *m->team;
+    const int gen = t.generation.load(std::memory_order_acquire);
+    if (t.arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == m->G) {
+        t.arrived.store(0, std::memory_order_relaxed);
+        t.generation.fetch_add(1, std::memory_order_release);
+    } else {
+        for (int spins = 0; t.generation.load(std::memory_order_acquire) == gen; ++spins) {
+            if (t.broken.load(std::memory_order_acquire)) return false;
+            if (spins > 4000) std::this_thread::yield();
         }
     }
-    // K1 in two halves: the positions (verlet.f90:58-63 + the unwrapped update) are final first, their exchange starts
-    // on the communication streams and the velocity half-kick (:72-74) runs beside it
-    bool split = m->overlap;
-    for (int g = 0; g < G; ++g) {
-        LJMD_HIP(h, hipSetDevice(m->dev[g]));
-        q[g] = next_events(m->eng[g]);
-        if (m->overlap) {
-            bool split_g = false;
-            LJMD_CHILD(h, m->eng[g], enqueue_drift_positions(m->eng[g], q[g], &split_g));
-            split = split && split_g;            // a re-sort step (the same on every rank) has already run all of K1
-        } else {
-            LJMD_CHILD(h, m->eng[g], enqueue_drift(m->eng[g], q[g]));
-        }
+    return !t.broken.load(std::memory_order_acquire);
+}
+
+int team_steps_rank(ljmd_multi *m, int g, int nsteps, bool sampled)
+{
+    ljmd_t *e = m->eng[g];
+    const bool barriers = m->xmode != kRccl && m->G > 1, fx = needs_force_exchange(e), guard = needs_pull_guard(m);
+    const bool keep = e->want_energy;
+    int rc_ = LJMD_OK;
+    auto sync = [&]() { if (rc_ == LJMD_OK && !team_barrier(m)) rc_ = LJMD_ERR_STATE; };   // another rank failed
+    for (int s = 0; s < nsteps && rc_ == LJMD_OK; ++s) {
+        if (sampled) e->want_energy = s == nsteps - 1;
+        RankStep st;
+        if (guard) sync();                         // the other ranks' "pulls done" events of the previous step exist
+        if (rc_ == LJMD_OK) rc_ = step_a(m, g, st);
+        if (barriers) sync();
+        if (rc_ == LJMD_OK && exchanges(m)) rc_ = pos_collect(m, g);
+        if (rc_ == LJMD_OK) rc_ = step_b(m, g, st);
+        if (barriers && fx) sync();
+        if (rc_ == LJMD_OK && fx) rc_ = force_collect(m, g);
+        if (rc_ == LJMD_OK) rc_ = step_c(m, g, st, true);
     }
-    LJMD_TRY(exchange_positions(h, q));
-    if (split)
-        for (int g = 0; g < G; ++g) {
-            LJMD_HIP(h, hipSetDevice(m->dev[g]));
-            LJMD_CHILD(h, m->eng[g], enqueue_drift_velocities(m->eng[g]));
+    e->want_energy = keep;
+    if (rc_ != LJMD_OK) m->team->broken.store(true, std::memory_order_release);   // releases the ranks waiting for this one
+    return rc_;
+}
+
+void team_worker(ljmd_multi *m, int g)
+{
+    StepTeam &t = *m->team;
+    (void)hipSetDevice(m->dev[g]);
+    unsigned seen = 0;
+    for (;;) {
+        int nsteps;
+        bool sampled;
+        {
+            std::unique_lock<std::mutex> lk(t.mu);
+            t.cv_go.wait(lk, [&] { return t.seq != seen || t.quit; });
+            if (t.quit) return;
+            seen = t.seq;
+            nsteps = t.nsteps;
+            sampled = t.sampled;
         }
-    LJMD_TRY(await_positions(h));
-    return enqueue_forces_all(h, true, q);
+        const int rc_ = team_steps_rank(m, g, nsteps, sampled);
+        {
+            std::lock_guard<std::mutex> lk(t.mu);
+            t.rc[g] = rc_;
+            ++t.done;
+        }
+        t.cv_done.notify_one();
+    }
+}
+
+int team_enqueue(ljmd_t *h, int nsteps, bool sampled)
+{
+    ljmd_multi *m = h->multi;
+    StepTeam &t = *m->team;
+    {
+        std::lock_guard<std::mutex> lk(t.mu);
+        t.arrived.store(0);
+        t.broken.store(false);
+        t.nsteps = nsteps;
+        t.sampled = sampled;
+        t.done = 0;
+        ++t.seq;
+    }
+    t.cv_go.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(t.mu);
+        t.cv_done.wait(lk, [&] { return t.done == m->G; });
+    }
+    for (int g = 0; g < m->G; ++g)                     // the rank that failed by itself, not the ones it released
+        if (t.rc[g] != LJMD_OK && !m->eng[g]->err.empty() && t.rc[g] != LJMD_ERR_STATE) return child_failed(h, m->eng[g], t.rc[g]);
+    for (int g = 0; g < m->G; ++g)
+        if (t.rc[g] != LJMD_OK) return child_failed(h, m->eng[g], t.rc[g]);
+    return LJMD_OK;
 }
 
 // reads the last `count` records of every rank and combines them step by step in rank order
@@ -419,6 +574,11 @@ int create(ljmd_t **out, int32_t n, double box_length, double dt, double rc, int
                 return fail(h, LJMD_ERR_HIP, "ncclCommInitAll over %d devices failed: %s", n_gpus, ncclGetErrorString(r));
             }
         }
+        if (n_gpus > 1 && env_int("LJMD_MULTI_THREADS", 1) != 0) {
+            m->team.reset(new StepTeam);
+            m->team->rc.assign(n_gpus, LJMD_OK);
+            for (int g = 0; g < n_gpus; ++g) m->team->threads.emplace_back(team_worker, m, g);
+        }
         return LJMD_OK;
     };
     const int rc_ = body();
@@ -436,6 +596,15 @@ void destroy(ljmd_t *h)
     if (!h) return;
     ljmd_multi *m = h->multi;
     if (m) {
+        if (m->team) {
+            {
+                std::lock_guard<std::mutex> lk(m->team->mu);
+                m->team->quit = true;
+            }
+            m->team->cv_go.notify_all();
+            for (std::thread &t : m->team->threads) t.join();
+            m->team.reset();
+        }
         for (size_t g = 0; g < m->eng.size(); ++g) {
             (void)hipSetDevice(m->dev[g]);
             if (m->eng[g]->stream) (void)hipStreamSynchronize(m->eng[g]->stream);
@@ -547,11 +716,9 @@ int set_observables(ljmd_t *h, bool on)
 
 int compute_forces(ljmd_t *h, double *epot, double *d_epot, double *dd_epot)
 {
-    ljmd_multi *m = h->multi;
-    const std::vector<EventSet *> q(m->G, nullptr);
     const bool keep = h->want_energy;
     set_observables(h, true);                   // this call exists to return the three sums
-    const int rc_ = enqueue_forces_all(h, false, q);
+    const int rc_ = enqueue_forces_all(h, false);
     set_observables(h, keep);
     if (rc_ != LJMD_OK) return rc_;
     h->have_accel = true;
@@ -673,6 +840,11 @@ int enqueue_steps(ljmd_t *h, int32_t nsteps, bool sampled)
     if (pending(h) + (unsigned)nsteps > kRingCap)
         return fail(h, LJMD_ERR_STATE, "ljmd_enqueue_steps: %u + %d pending steps exceed LJMD_MAX_PENDING_STEPS", pending(h),
                     nsteps);
+    if (h->multi->team) {
+        const int rc_ = team_enqueue(h, nsteps, sampled);
+        if (rc_ != LJMD_OK) h->poisoned = true;    // some ranks are a phase ahead of the others
+        return rc_;
+    }
     const bool keep = h->want_energy;
     for (int s = 0; s < nsteps; ++s) {
         if (sampled) set_observables(h, s == nsteps - 1);

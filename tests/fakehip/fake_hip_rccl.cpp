@@ -9,9 +9,12 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -23,7 +26,7 @@ int fake_devices()
 thread_local int t_device = 0;
 struct CallCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local std::vector<CallCfg> t_cfg;
-long g_launches = 0, g_copies = 0, g_collectives = 0;
+std::atomic<long> g_launches{0}, g_copies{0}, g_collectives{0};
 }  // namespace
 
 extern "C" {
@@ -166,11 +169,47 @@ ncclResult_t run_ops(std::vector<Op> &ops)
     return ncclSuccess;
 }
 
+// one host thread per rank (the library's StepTeam): every thread calls its own communicator outside any group, and the
+// collective completes when the last rank has arrived -- a rendezvous across the threads of this process
+std::mutex g_mu;
+std::condition_variable g_cv;
+std::vector<Op> g_waiting;
+unsigned long g_completed = 0;                               // collectives carried out through the rendezvous
+
+ncclResult_t rendezvous(const Op &o)
+{
+    std::unique_lock<std::mutex> lk(g_mu);
+    g_waiting.push_back(o);
+    std::vector<Op> mine;
+    for (const Op &p : g_waiting)
+        if (p.kind == o.kind && p.comm->group == o.comm->group) mine.push_back(p);
+    if ((int)mine.size() < o.comm->nranks) {
+        const unsigned long seen = g_completed;
+        // (a rank that never arrives would hang real RCCL as well; the test's own timeout ends such a run)
+        g_cv.wait(lk, [&] {
+            if (g_completed == seen) return false;
+            for (const Op &p : g_waiting)
+                if (p.comm == o.comm && p.kind == o.kind) return false;      // still queued: another group completed
+            return true;
+        });
+        return ncclSuccess;
+    }
+    std::vector<Op> rest;
+    for (const Op &p : g_waiting)
+        if (!(p.kind == o.kind && p.comm->group == o.comm->group)) rest.push_back(p);
+    g_waiting.swap(rest);
+    const ncclResult_t r = run_ops(mine);
+    ++g_completed;
+    g_cv.notify_all();
+    return r;
+}
+
 ncclResult_t submit(const Op &o)
 {
+    if (t_depth == 0 && o.comm->nranks != 1 && (o.kind == kAllGather || o.kind == kReduceScatter)) return rendezvous(o);
     t_ops.push_back(o);
     if (t_depth > 0) return ncclSuccess;
-    if (o.comm->nranks != 1) {                               // outside a group only a 1-rank communicator can make progress
+    if (o.comm->nranks != 1) {                               // ungrouped send / recv between ranks: not supported here
         t_ops.clear();
         return ncclInvalidUsage;
     }

@@ -72,6 +72,9 @@ for n, devices, env in ((16384, [0, 1], {}), (16384, [0, 1, 2, 3], {}), (32768, 
                         (16384, [0, 1, 2, 3], {"LJMD_MULTI_EXCHANGE": "host", "LJMD_MULTI_MIGRATE_EVERY": "7"}),   # pinned-host staging
                         (4096, [1, 3], {"LJMD_N3": "0", "LJMD_MULTI_EXCHANGE": "host"}),
                         (16384, [0, 1, 2, 3], {"LJMD_OVERLAP_EXCHANGE": "0"}),         # exchanges on the engine streams
+                        (16384, [0, 1, 2, 3], {"LJMD_MULTI_THREADS": "0"}),            # one host thread for all ranks, grouped RCCL
+                        (16384, [0, 0, 0, 0], {"LJMD_MULTI_THREADS": "0", "LJMD_MULTI_EXCHANGE": "host"}),
+                        (3072, [0, 1, 2], {"LJMD_N3": "0"}),                           # gather kernels, RCCL, one thread per rank
                         (12288, [0, 1, 2], {"LJMD_MULTI_EXCHANGE": "copy", "LJMD_N3_MIN_N": "1", "LJMD_MULTI_MIGRATE_EVERY": "3"}),
                         (24576, [0, 1, 2], {"LJMD_N3_ROW_TILES": "4", "LJMD_N3_WG_WAVES": "2", "LJMD_N3_MIN_N": "1"})):
     os.environ.update(env)
