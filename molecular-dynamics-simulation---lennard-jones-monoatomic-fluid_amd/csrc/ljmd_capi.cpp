@@ -94,6 +94,8 @@ N3Args n3_args(ljmd_t *h)
     a.Q = h->Q;
     a.dchunk = h->dchunk;
     a.xcd_remap = 0;
+    a.inline_class = (h->fuse_tail && h->rt == 1 && h->wg_waves == 1) ? 1 : 0;
+    a.rc2_skin = h->rc2 * (1.0 + 1e-10);
     a.energy = h->want_energy ? 1 : 0;
     a.RT = h->rt;
     a.L = h->L;
@@ -155,6 +157,7 @@ FinalizeArgs finalize_args(ljmd_t *h, int n_wg, bool with_ke, double pair_scale)
     a.pair_scale = pair_scale;
     a.wg_part = h->d_wg_part;
     a.ke_part = h->d_ke_part;
+    a.ke_tile = nullptr;
     a.ring = h->d_ring;
     a.ring_pos = h->d_ring_pos;
     a.n_wg = n_wg;
@@ -275,7 +278,9 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (!h->use_n3) ga.mask_far = nullptr;
         if (!h->boxes_valid) LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
         h->boxes_valid = false;                    // good for this evaluation only
-        if (h->use_n3)      // tile-pair test + pass descriptors of the Newton-3 kernels in one launch (mixed mode: NEAR and FAR)
+        if (h->use_n3 && h->fuse_tail)
+            ;               // small single-rank system: the pair kernel's waves work their pass descriptors out themselves
+        else if (h->use_n3)      // tile-pair test + pass descriptors of the Newton-3 kernels in one launch (mixed mode: NEAR and FAR)
             LJMD_HIP(h, launch_tile_class(ga, h->invL, h->rc2, h->S, h->NGo, h->d_desc,
                                           h->mode == LJMD_PRECISION_FP32_FORCE ? h->d_desc_far : nullptr, h->d_desc2, h->stream));
         else                // the gather kernel reads the bit mask
@@ -325,7 +330,13 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         n_wg = grid.x * grid.y;
     }
     if (q) LJMD_HIP(h, hipEventRecord(q->e[3], h->stream));
-    LJMD_HIP(h, launch_reduce_forces(reduce_args(h, nslab, n3), needs_force_exchange(h), h->stream));
+    h->reduce_deferred = fast && h->fuse_tail && h->kick_hint >= 0 && n_wg <= 4096 && !needs_force_exchange(h);
+    if (h->reduce_deferred) {            // the tail launch of enqueue_kick reduces, kicks and folds the record in one kernel
+        h->deferred_nslab = nslab;
+        h->deferred_n3 = n3;
+    } else {
+        LJMD_HIP(h, launch_reduce_forces(reduce_args(h, nslab, n3), needs_force_exchange(h), h->stream));
+    }
     h->forces_pending = true;
     h->pending_n_wg = n_wg;
     h->pending_scale = n3 ? 1.0 : 0.5;
@@ -336,6 +347,25 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
 // second half-kick, kinetic-energy partials and this step's partial record.
 int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
 {
+    if (h->reduce_deferred) {
+        h->reduce_deferred = false;
+        const bool drift = kick && h->next_drift_hint;
+        IntegrateArgs ia = integrate_args(h);
+        ia.ticket = h->d_ticket;
+        if (drift) {                     // the next step's K1 writes the tile boxes and the coherent copy as well
+            ia.bbox = h->d_bbox;
+            ia.pos_tc = h->use_n3 ? h->d_pos_tc : nullptr;
+        }
+        FinalizeArgs fa = finalize_args(h, h->pending_n_wg, kick, h->pending_scale);
+        fa.ke_tile = h->d_ke_tile;
+        LJMD_HIP(h, launch_tile_tail(reduce_args(h, h->deferred_nslab, h->deferred_n3), ia, fa, kick, drift, h->stream));
+        if (q) LJMD_HIP(h, hipEventRecord(q->e[4], h->stream));
+        h->drift_prefused = drift;
+        h->ring_issued++;
+        h->have_accel = true;
+        h->forces_pending = false;
+        return LJMD_OK;
+    }
     if (needs_force_exchange(h) && !h->external_force_exchange) {
         if (!h->comm) return fail(h, LJMD_ERR_STATE, "multi-rank Newton-3 step: call ljmd_comm_init first");
         const bool cs = use_comm_stream(h);
@@ -386,10 +416,16 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
     return LJMD_OK;
 }
 
-int enqueue_forces(ljmd_t *h, bool kick, EventSet *q)
+int enqueue_forces(ljmd_t *h, bool kick, EventSet *q, bool next_drift)
 {
-    const int rc_ = enqueue_pair_forces(h, q);
-    return rc_ != LJMD_OK ? rc_ : enqueue_kick(h, kick, q);
+    h->kick_hint = kick ? 1 : 0;         // both phases from one caller: the tail launch may take everything behind the pair kernel
+    h->next_drift_hint = next_drift;
+    int rc_ = enqueue_pair_forces(h, q);
+    if (rc_ == LJMD_OK) rc_ = enqueue_kick(h, kick, q);
+    h->kick_hint = -1;
+    h->next_drift_hint = false;
+    h->reduce_deferred = false;
+    return rc_;
 }
 
 // K1, positions: drift + wrap + unwrapped update.  On a re-sort step (and only then) the whole of K1 runs here, followed
@@ -449,6 +485,14 @@ int enqueue_drift(ljmd_t *h, EventSet *q)
     if (q) LJMD_HIP(h, hipEventRecord(q->e[0], h->stream));
     h->gather_done_for_step = false;
     const bool resort_now = h->sort_enabled && fast_path_ok(h) && h->steps_since_sort + 1 >= h->resort_every;
+    if (h->drift_prefused) {
+        // the previous step's tail launch has already run this K1 (tile_tail_kernel<.., DRIFT>), boxes included
+        h->drift_prefused = false;
+        h->boxes_valid = !resort_now && fast_path_ok(h);
+        h->positions_compact = true;
+        if (h->sort_enabled && fast_path_ok(h) && ++h->steps_since_sort >= h->resort_every) return resort(h, false);
+        return LJMD_OK;
+    }
     IntegrateArgs ia = integrate_args(h);
     // single rank, no re-sort behind this kernel: the drift kernel's waves are the tiles -- let them write
     // the bounding boxes of the new positions and skip tile_boxes_kernel in the force evaluation that follows
@@ -523,7 +567,7 @@ void release(ljmd_t *h)
                    h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv, h->d_fall,
                    h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket,
-                   h->d_desc, h->d_desc_far, h->d_desc2, h->d_pos_tc, h->d_gid0, h->d_mig, h->d_mig_idx, h->d_mig_idx2, h->d_mig_keys,
+                   h->d_desc, h->d_desc_far, h->d_desc2, h->d_ke_tile, h->d_pos_tc, h->d_gid0, h->d_mig, h->d_mig_idx, h->d_mig_idx2, h->d_mig_keys,
                    h->d_mig_keys2, h->d_mig_offsets, h->d_mig_cub};
     for (void *p : dev) (void)hipFree(p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -813,7 +857,10 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     // (Most of the slow-down once measured between two sorts -- +9 % after 9 steps in the liquid -- came from tiles that
     // straddle a box face; the tile-coherent positions of tile_boxes_kernel removed it, and 10 / 15 / 20 / 30 steps now
     // differ by < 3 % at n = 262144.)
-    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", n >= 1000000 ? 5 : n >= 131072 ? 10 : 20));
+    // Small systems (n <= 8192): one re-sort is ~30 launches = 135 us against a 33 us step, and in 200 steps a particle of
+    // the liquid moves ~0.5 sigma against tiles of 4.3 sigma: every 200 steps (20: 25 300 steps/s at n = 4096, 100: 29 500,
+    // 200: 30 000, 400: 30 500 -- tools/small_n_rate.py, profiles/r03_small_n_two_launch_step.txt).
+    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", n >= 1000000 ? 5 : n >= 131072 ? 10 : n > 8192 ? 20 : 200));
     h->ncell = std::max(1, std::min(1023, (int)std::floor(box_length / 1.2)));
     h->kd_sort = env_int("LJMD_SORT_KD", 1) != 0;
     std::vector<int> kd_offsets;
@@ -895,9 +942,16 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         int ns = (target_waves + h->NGo - 1) / h->NGo;
         const int n_off = h->Dmax + h->wg_waves;          // offsets a workgroup walks (relative to its first row group)
         ns = std::max(1, std::min(ns, n_off));
+        // small single-rank systems: at most 4096 work items, so that the step record is folded by ONE block whichever
+        // way the step is launched (the fused step kernel keeps finalize_body's summation order, not fold_partials')
+        const bool small_single = n_ranks == 1 && n <= 8192 && rt == 1;
+        if (small_single) ns = std::max(1, std::min(ns, 4096 / std::max(1, h->NGo)));
         h->dchunk = (n_off + ns - 1) / ns;
         h->nslab_n = (n_off + h->dchunk - 1) / h->dchunk;
     }
+    // two launches per step for small single-rank systems (tile_tail_kernel; ljmd_engine.h: fuse_tail)
+    h->fuse_tail = h->fuse_small && env_int("LJMD_FUSE_TAIL", 1) != 0 && n_ranks == 1 && n <= 8192 && h->rc_allows_fast &&
+                   precision_mode == LJMD_PRECISION_FP64 && (!h->use_n3 || (h->rt == 1 && h->wg_waves == 1));
     const bool mixed = precision_mode == LJMD_PRECISION_FP32_FORCE;
     if (mixed && (!h->use_n3 || n < kMixedMinN)) {
         // the fp32 far kernel works on 4-tile row groups and only pays where most pairs are far pairs
@@ -952,6 +1006,10 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_fold, 2 * (size_t)kFoldBlocks * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ticket, sizeof(unsigned)));
         LJMD_HIP(h, hipMemsetAsync(h->d_ticket, 0, sizeof(unsigned), h->stream));
+        if (h->fuse_tail) {
+            LJMD_HIP(h, hipMalloc(&h->d_ke_tile, 3 * (size_t)h->T * sizeof(double)));
+            LJMD_HIP(h, hipMemsetAsync(h->d_ke_tile, 0, 3 * (size_t)h->T * sizeof(double), h->stream));
+        }
         LJMD_HIP(h, hipMalloc(&h->d_ring, (size_t)kRingCap * kPartialStride * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring_pos, sizeof(unsigned)));
         LJMD_HIP(h, hipMalloc(&h->d_bbox, (size_t)h->T * kBoxStride * sizeof(double)));
@@ -1015,6 +1073,7 @@ int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *
         return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_set_state: NULL array");
     if (h->multi) return ljmdm::set_state(h, rx, ry, rz, vx, vy, vz);
     h->boxes_valid = false;
+    h->drift_prefused = false;
     LJMD_HIP(h, hipSetDevice(h->device));
     if (h->poisoned) {
         // a batch of steps failed half-way: drain the stream, forget whatever records were in flight and take the
@@ -1189,7 +1248,7 @@ int ljmd_verlet_steps(ljmd_t *h, int32_t nsteps, double *epot, double *ekin, dou
         for (int s = 0; s < batch; ++s) {
             EventSet *q = next_events(h);
             int rc_ = enqueue_drift(h, q);
-            if (rc_ == LJMD_OK) rc_ = enqueue_forces(h, true, q);
+            if (rc_ == LJMD_OK) rc_ = enqueue_forces(h, true, q, s + 1 < batch);
             if (rc_ != LJMD_OK) {
                 h->want_energy = keep;
                 h->poisoned = true;      // a step is half enqueued: no rollback, the state is no longer a trajectory point
@@ -1257,7 +1316,7 @@ int enqueue_steps_impl(ljmd_t *h, int32_t nsteps, bool sampled)
         EventSet *q = next_events(h);
         if (sampled) h->want_energy = s == nsteps - 1;
         int rc_ = enqueue_drift(h, q);
-        if (rc_ == LJMD_OK) rc_ = enqueue_forces(h, true, q);
+        if (rc_ == LJMD_OK) rc_ = enqueue_forces(h, true, q, s + 1 < nsteps);
         if (rc_ != LJMD_OK) {
             h->want_energy = keep;
             h->poisoned = true;

@@ -95,6 +95,18 @@ struct ljmd {
     int xcd_min_groups = 256;     // row groups per rank from which the XCD-aware mapping is used
     int xcd_remap = 0;            // LJMD_N3_XCD_REMAP: consecutive row groups per XCD chunk of the Newton-3 pair kernel (0 = plain mapping)
     bool fuse_small = true;       // LJMD_FUSE: boxes inside the drift kernel, finalize inside the kick kernel
+    // LJMD_FUSE_TAIL (default on): small single-rank systems run a step as TWO launches -- the pair kernel with its pass
+    // descriptors worked out in-kernel, and tile_tail_kernel (slab reduction + kick + step record + the NEXT step's K1).
+    // kick_hint / next_drift_hint: what the caller of enqueue_pair_forces already knows about the rest of the step (-1 = not
+    // known: the split-phase API); reduce_deferred: the pair phase left the reduction to the tail launch of enqueue_kick;
+    // drift_prefused: the previous step's tail has already run this step's K1
+    bool fuse_tail = false;
+    int kick_hint = -1;
+    bool next_drift_hint = false;
+    bool reduce_deferred = false, deferred_n3 = false;
+    int deferred_nslab = 0;
+    bool drift_prefused = false;
+    double *d_ke_tile = nullptr;      // [T][3] per-tile sums of v^2
     bool boxes_valid = false;     // d_bbox already holds the boxes of the current positions (written by the drift kernel)
     double *d_ke_part = nullptr;  // [n_ke][3]
     double *d_ring = nullptr;     // [kRingCap][kPartialStride]
@@ -210,6 +222,8 @@ int enqueue_drift_positions(ljmd_t *h, EventSet *q, bool *split);
 int enqueue_drift_velocities(ljmd_t *h);
 int enqueue_pair_forces(ljmd_t *h, EventSet *q);
 int enqueue_kick(ljmd_t *h, bool kick, EventSet *q);
+// both phases from one caller; next_drift: another step follows in the same batch (its K1 may ride on this step's tail launch)
+int enqueue_forces(ljmd_t *h, bool kick, EventSet *q, bool next_drift = false);
 int fetch_ring(ljmd_t *h, unsigned count);
 void combine_one(const ljmd_t *h, const double *recs, int n_ranks, double *epot, double *ekin, double *d_epot,
                  double *dd_epot);

@@ -66,7 +66,9 @@ struct N3Args {
     int dchunk;             // offsets d per grid.y slice
     int energy;             // 0: forces only -- the energy sums are not accumulated and the workgroup partials are NaN
     int xcd_remap;          // C > 0: XCD-aware mapping, chunks of C consecutive row groups per XCD (gridDim.x % (8 C) == 0)
+    int inline_class;       // RT = 1, one wave per workgroup: the waves compute their pass descriptors themselves (desc unused)
     double L, invL, rc2;
+    double rc2_skin;        // rc^2 (1 + 1e-10) of the tile-pair test (GeometryArgs::rc2_skin), for inline_class
 };
 
 struct IntegrateArgs {
@@ -103,6 +105,7 @@ struct ReduceArgs {
 struct FinalizeArgs {
     const double *wg_part;
     const double *ke_part;
+    const double *ke_tile;  // NULL, or [T][3] per-tile sums of v^2 (tile_tail_kernel) to be combined per 256-slot block
     double *ring;           // [ring_cap][kPartialStride]
     unsigned *ring_pos;     // device counter, bumped once per finalize
     int n_wg, n_ke;
@@ -142,7 +145,7 @@ struct SortArgs {
 
 hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s);   // dispatches on a.RT, wg_waves
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s, size_t dyn_lds = 0);   // dispatches on a.RT, wg_waves
 hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, int phase /* 0 all, 1 positions, 2 velocities */, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);
@@ -153,6 +156,10 @@ hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);
 // out[i] = blocks[0][i] + blocks[1][i] + ... + blocks[G-1][i], i < len (left to right: the order is part of the result)
 hipError_t launch_sum_blocks(const double *blocks, double *out, int G, int len, hipStream_t s);
 hipError_t launch_finalize(const FinalizeArgs &a, double *fold_scratch /* [2 * kFoldBlocks] or NULL */, hipStream_t s);
+// small single-rank systems: slab reduction + kick + step record (+ the next step's K1 when drift) in one launch, one
+// block per tile; kick without drift = the last step of a batch, neither = a plain force evaluation
+hipError_t launch_tile_tail(const ReduceArgs &ra, const IntegrateArgs &a, const FinalizeArgs &f, bool kick, bool drift,
+                            hipStream_t s);
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s);

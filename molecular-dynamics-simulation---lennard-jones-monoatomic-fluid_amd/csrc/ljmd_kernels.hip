@@ -832,6 +832,10 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
 #undef LJMD_LOOP
 }
 
+// (defined with the geometry pre-pass below)
+__device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, double rc2, int S, int Al, int c,
+                                           unsigned &desc_out, unsigned *desc_far, float *desc2);
+
 template <int MIN_WAVES, int RT, int W, bool ENERGY>
 __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
 {
@@ -895,7 +899,23 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         desc = 0;
         if (owned) {
             // wave-uniform by construction: keep it in SGPRs so that the per-row-tile tests are scalar branches
-            desc = (unsigned)__builtin_amdgcn_readfirstlane((int)a.desc[(size_t)Al * a.T + c]);
+            if constexpr (RT == 1 && W == 1) {
+                // small single-rank systems (N3Args::inline_class): the wave works its pass descriptor out itself
+                // -- the same function tile_class_kernel runs -- and the step saves a launch
+                if (a.inline_class) {
+                    GeometryArgs ga;
+                    ga.pos = nullptr; ga.bbox = const_cast<double *>(a.bbox); ga.pos_tc = nullptr; ga.mask = nullptr; ga.mask_far = nullptr;
+                    ga.P = a.P; ga.G = a.G; ga.rank = a.rank; ga.TB = a.TB; ga.T = a.T; ga.W = a.W; ga.RT = 1;
+                    ga.L = a.L; ga.invL = a.invL; ga.rc2_skin = a.rc2_skin; ga.rsplit2 = 0.0;
+                    unsigned dsc = 0;
+                    (void)tile_class(ga, a.invL, a.rc2, a.S, Al, c, dsc, nullptr, nullptr);
+                    desc = (unsigned)__builtin_amdgcn_readfirstlane((int)dsc);
+                } else {
+                    desc = (unsigned)__builtin_amdgcn_readfirstlane((int)a.desc[(size_t)Al * a.T + c]);
+                }
+            } else {
+                desc = (unsigned)__builtin_amdgcn_readfirstlane((int)a.desc[(size_t)Al * a.T + c]);
+            }
             mb = desc & 15u;
             if (d == 0) mb &= (2u << l) - 1u;              // diagonal group: row tile k <= column tile l
         }
@@ -1295,19 +1315,17 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
 // Same expressions as the former in-kernel classification; the row group's box is the union of its tiles' exact
 // boxes (= min / max over its 256 particles).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, double invL, double rc2, int S, unsigned *desc,
-                                                            unsigned *desc_far, float *desc2)
+// -> false: the pair kernel does not visit (row group Al, column tile c).  desc_far / desc2: NULL = not wanted.
+__device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, double rc2, int S, int Al, int c,
+                                           unsigned &desc_out, unsigned *desc_far, float *desc2)
 {
-    const int c = blockIdx.x * kBlock + threadIdx.x;           // column tile (global)
-    const int Al = blockIdx.y;                                 // owned row group
-    if (c >= a.T) return;
     const int RT = a.RT;
     {   // only the (row group, column group) pairs the pair kernel visits: offset d = (B - A) mod NG in 0 .. NG / 2,
         // the pair at exactly NG / 2 from its lower-numbered side (pair_n3_kernel's own_pair)
         const int NG = a.T / RT, A = a.rank * (a.TB / RT) + Al, B = c / RT;
         int d = B - A;
         if (d < 0) d += NG;
-        if (!(d == 0 || 2 * d < NG || (2 * d == NG && A < B))) return;
+        if (!(d == 0 || 2 * d < NG || (2 * d == NG && A < B))) return false;
     }
     double glo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
     double ghi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
@@ -1426,8 +1444,19 @@ __global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, doub
             }
         }
     }
-    desc[(size_t)Al * a.T + c] = mb | cls;
+    desc_out = mb | cls;
     if (desc_far) desc_far[(size_t)Al * a.T + c] = mb_far | cls;
+    return true;
+}
+
+__global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, double invL, double rc2, int S, unsigned *desc,
+                                                            unsigned *desc_far, float *desc2)
+{
+    const int c = blockIdx.x * kBlock + threadIdx.x;           // column tile (global)
+    const int Al = blockIdx.y;                                 // owned row group
+    if (c >= a.T) return;
+    unsigned d = 0;
+    if (tile_class(a, invL, rc2, S, Al, c, d, desc_far, desc2)) desc[(size_t)Al * a.T + c] = d;
 }
 
 // ---------------------------------------------------------------------------
@@ -1656,9 +1685,18 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs &a, double *red
         v[1] += a.wg_part[2 * (size_t)w + 1];
     }
     for (int b = threadIdx.x; b < a.n_ke; b += kBlock) {
-        v[2] += a.ke_part[3 * (size_t)b];
-        v[3] += a.ke_part[3 * (size_t)b + 1];
-        v[4] += a.ke_part[3 * (size_t)b + 2];
+        if (a.ke_tile) {
+            // per-TILE sums (tile_tail_kernel): the 256-slot block's partial as kick_kernel forms it -- its four waves'
+            // sums added in order -- so that the record has the same bits whichever kernels produced it
+            const double *w = a.ke_tile + 3 * (size_t)(kWavesPerBlock * b);
+            v[2] += ((w[0] + w[3]) + w[6]) + w[9];
+            v[3] += ((w[1] + w[4]) + w[7]) + w[10];
+            v[4] += ((w[2] + w[5]) + w[8]) + w[11];
+        } else {
+            v[2] += a.ke_part[3 * (size_t)b];
+            v[3] += a.ke_part[3 * (size_t)b + 1];
+            v[4] += a.ke_part[3 * (size_t)b + 2];
+        }
     }
     block_sum<5>(v, red);
     if (threadIdx.x == 0) {
@@ -1713,6 +1751,140 @@ __global__ __launch_bounds__(kBlock) void kick_finalize_kernel(IntegrateArgs a, 
             w[1] = k2[1];
             w[2] = k2[2];
         }
+        __threadfence();                                   // this block's partial is visible device-wide ...
+        last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;   // ... before its ticket is
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                       // the other blocks' partials, fresh from L2
+    finalize_body(f, red);
+    if (threadIdx.x == 0) *a.ticket = 0u;                  // ready for the next launch (stream-ordered)
+}
+
+// ---------------------------------------------------------------------------
+// Small single-rank systems (the reference's own range, BASELINE configs 1-2): a step is bound by the latency CHAIN of
+// its dependent launches -- five kernels of 4-19 us at n = 4096 -- not by any of them.  tile_tail_kernel is everything
+// behind the pair kernel AND, inside a batch of steps, the next step's K1, one 256-thread block per tile:
+//   K3a  the tile's partial accelerations, the four waves splitting the terms as reduce_forces_kernel does;
+//   K3b  x24, second half-kick, sum v^2 per tile (wave 0; lj_potential_energy.f90:189-191, verlet.f90:86-95);
+//   K1'  DRIFT: the NEXT step's drift + wrap + first half-kick + unwrapped update of the tile's 64 particles
+//        (verlet.f90:58-74, md_simulation_program.f90:341-351 -- a particle's K1 reads only its own r, v, a), the tile's
+//        coherent copy and its bounding box, as drift_kick_kernel<0, true> writes them;
+//   K4   ONE ticket per block; the block that draws the last one folds the step's record (finalize_body).
+// With the pass descriptors worked out inside the pair kernel (N3Args::inline_class) a step is TWO launches.  Same
+// expressions, same summation orders as the separate kernels: bit-identical results
+// (tests/test_gpu_parity.py::test_fused_launches_are_bitwise_equal_to_the_separate_kernels).  A first attempt that put
+// the pair loop into the same launch (tickets per tile, one device-scope fence pair per WAVE) was 3.4x slower than five
+// launches: profiles/r03_small_n_single_launch_negative.txt.
+// ---------------------------------------------------------------------------
+template <bool N3, bool KICK, bool DRIFT>
+__global__ __launch_bounds__(kBlock) void tile_tail_kernel(ReduceArgs ra, IntegrateArgs a, FinalizeArgs f)
+{
+    __shared__ double part[kWavesPerBlock][3][kTile];
+    __shared__ double red[5 * kWavesPerBlock];
+    __shared__ bool last;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int tile = blockIdx.x;
+    const int i = tile * kTile + lane;                          // slot
+    // wave 0 integrates the tile behind the reduction: its loads go out first and arrive while the partial sums are formed
+    double v_in[3] = {0.0, 0.0, 0.0}, r_in[3] = {0.0, 0.0, 0.0}, ru_in[3] = {0.0, 0.0, 0.0};
+    if (q == 0) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const size_t o = (size_t)ax * a.P + i;
+            if constexpr (KICK || DRIFT) v_in[ax] = a.v[o];
+            if constexpr (DRIFT) {
+                r_in[ax] = a.r[o];
+                ru_in[ax] = a.ru[o];
+            }
+        }
+    }
+    double s[3] = {0.0, 0.0, 0.0};
+    // The order of reduce_forces_kernel (single rank): the row-side slices, then the column-side blocks, wave q taking
+    // the terms q, q + 4, ...  A block that was not written this step (flag 0) adds an exact zero here instead of being
+    // skipped -- s + 0.0 == s -- so that the loads do not depend on the flags and are in flight together: the chain of
+    // ~17 dependent load-and-add round trips per wave was half of this kernel's 17 us at n = 4096.
+#pragma unroll 4
+    for (int c = q; c < ra.nslab; c += kWavesPerBlock) {
+        const double *sl = ra.slab + (size_t)c * 3 * ra.P + i;
+        s[0] += sl[0];
+        s[1] += sl[ra.P];
+        s[2] += sl[2 * (size_t)ra.P];
+    }
+    if constexpr (N3) {
+        const int B = tile / ra.RT, l = tile - B * ra.RT;
+        const int nwg = (ra.NGo + ra.WG - 1) / ra.WG;
+#pragma unroll 4
+        for (int gi = q; gi < nwg; gi += kWavesPerBlock) {
+            int e = B - gi * ra.WG;
+            if (e < 0) e += ra.NG;
+            const bool mine = e <= ra.Dmax + ra.WG - 1;
+            const size_t blk = mine ? (size_t)gi * ra.Q + (size_t)e * ra.RT + l : 0;
+            const bool on = mine && ra.flag_j[blk] != 0;
+            const double *b = ra.slab_j + blk * (3 * kTile) + lane;
+            const double b0 = b[0], b1 = b[kTile], b2 = b[2 * kTile];      // (whatever an unwritten block holds is discarded)
+            s[0] += on ? b0 : 0.0;
+            s[1] += on ? b1 : 0.0;
+            s[2] += on ? b2 : 0.0;
+        }
+    }
+    part[q][0][lane] = s[0];
+    part[q][1][lane] = s[1];
+    part[q][2][lane] = s[2];
+    __syncthreads();
+    if (q == 0) {
+        double k2[3] = {0.0, 0.0, 0.0}, rn[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            double t = part[0][ax][lane];
+#pragma unroll
+            for (int w = 1; w < kWavesPerBlock; ++w) t += part[w][ax][lane];
+            const size_t o = (size_t)ax * a.P + i;
+            const double acc = 24.0 * t;                        // kick_kernel
+            a.a[o] = acc;
+            double vel = v_in[ax];
+            if constexpr (KICK) {
+                vel = vel + acc * a.dt_half;
+                k2[ax] = vel * vel;
+            }
+            if constexpr (DRIFT) {                              // drift_kick_kernel<0> of the next step
+                const double r0 = r_in[ax];
+                double r1 = (r0 + vel * a.dt) + acc * a.dt_sq_half;
+                r1 = r1 - a.L * __builtin_floor(r1 * a.invL);
+                double d = r1 - r0;
+                d = d - a.L * __builtin_round(d * a.invL);
+                a.r[o] = r1;
+                a.ru[o] = ru_in[ax] + d;
+                rn[ax] = r1;
+                vel = vel + acc * a.dt_half;
+            }
+            if constexpr (KICK || DRIFT) a.v[o] = vel;
+        }
+        if constexpr (KICK) {
+            const double kx = wave_sum(k2[0]), ky = wave_sum(k2[1]), kz = wave_sum(k2[2]);
+            if (lane == 0) {
+                double *w = const_cast<double *>(f.ke_tile) + 3 * (size_t)tile;
+                w[0] = kx; w[1] = ky; w[2] = kz;
+            }
+        }
+        if constexpr (DRIFT) {
+            if (a.pos_tc) {                                     // tile frame: one tile per row group here (RT = 1)
+#pragma unroll
+                for (int ax = 0; ax < 3; ++ax) {
+                    rn[ax] = tile_frame(rn[ax], wave_first(rn[ax]), a.L, a.invL);
+                    a.pos_tc[(size_t)ax * a.P + i] = rn[ax];
+                }
+            }
+            const double lx = wave_min(rn[0]), ly = wave_min(rn[1]), lz = wave_min(rn[2]);
+            const double hx = wave_max(rn[0]), hy = wave_max(rn[1]), hz = wave_max(rn[2]);
+            if (lane == 0) {
+                double *o = a.bbox + (size_t)tile * kBoxStride;
+                o[0] = lx; o[1] = ly; o[2] = lz;
+                o[3] = hx; o[4] = hy; o[5] = hz;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
         __threadfence();                                   // this block's partial is visible device-wide ...
         last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;   // ... before its ticket is
     }
@@ -1791,15 +1963,16 @@ hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s)
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s, size_t dyn_lds)
 {
     // 3 waves per SIMD (168 VGPRs, no spills) is the measured optimum of the register budget; wg_waves = waves
     // (= consecutive row groups) per workgroup, 2 and 4 only for 4-tile row groups
     // a.energy == 0 (forces only) exists for the one-wave workgroups; the LDS-combining forms always keep the sums
+    // (dyn_lds: unused dynamic LDS that only limits how many waves share a CU -- small systems, see ljmd_create)
     if (a.RT == 1 && !a.energy)
-        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, false>), grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, false>), grid, dim3(kTile), dyn_lds, s, a);
     else if (a.RT == 1)
-        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, true>), grid, dim3(kTile), 0, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, true>), grid, dim3(kTile), dyn_lds, s, a);
     else if (a.RT == 2 && !a.energy)
         hipLaunchKernelGGL((pair_n3_kernel<3, 2, 1, false>), grid, dim3(kTile), 0, s, a);
     else if (a.RT == 2)
@@ -1912,6 +2085,24 @@ hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s)
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s)
 {
     hipLaunchKernelGGL(rdf_histogram_kernel, grid, dim3(kBlock), (size_t)a.nbins * sizeof(unsigned), s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_tail(const ReduceArgs &ra, const IntegrateArgs &a, const FinalizeArgs &f, bool kick, bool drift, hipStream_t s)
+{
+    const dim3 grid(a.P / kTile), block(kBlock);
+    const bool n3 = ra.slab_j != nullptr;
+#define LJMD_TAIL(N3_, KICK_, DRIFT_) hipLaunchKernelGGL((tile_tail_kernel<N3_, KICK_, DRIFT_>), grid, block, 0, s, ra, a, f)
+    if (n3) {
+        if (kick && drift) LJMD_TAIL(true, true, true);
+        else if (kick) LJMD_TAIL(true, true, false);
+        else LJMD_TAIL(true, false, false);
+    } else {
+        if (kick && drift) LJMD_TAIL(false, true, true);
+        else if (kick) LJMD_TAIL(false, true, false);
+        else LJMD_TAIL(false, false, false);
+    }
+#undef LJMD_TAIL
     return hipGetLastError();
 }
 

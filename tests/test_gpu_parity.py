@@ -834,23 +834,31 @@ def test_config2_10000_steps_vs_the_references_own_series():
     assert abs(Pm / Pr - 1.0) < 2e-2
 
 
-@pytest.mark.parametrize("n", [500, 4096, 32768])
+@pytest.mark.parametrize("n", [108, 500, 3000, 4096, 5000, 8192, 32768])
 def test_fused_launches_are_bitwise_equal_to_the_separate_kernels(n, monkeypatch):
     """LJMD_FUSE=1 (default): tile boxes written by the drift kernel, finalize folded into the kick kernel through
-    a last-block ticket.  Same values, same reductions, same order -> the same bits as the separate launches."""
+    a last-block ticket -- and, for single-rank systems of up to 8192 particles (LJMD_FUSE_TAIL), a step in TWO launches:
+    the pair kernel working its pass descriptors out itself, and tile_tail_kernel (slab reduction + kick + step record +
+    the next step's drift / wrap / half-kick / boxes, one block per tile).  Same values, same reductions, same order ->
+    the same bits as the separate launches, sampled (forces-only) segments included."""
     p, r, v = synthetic.make_config(n, seed=9)
     out = []
-    for fuse in ("1", "0"):
+    for fuse, step in (("1", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("LJMD_FUSE", fuse)
+        monkeypatch.setenv("LJMD_FUSE_TAIL", step)
         with Engine(p) as eng:
             eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
             e0 = eng.compute_forces()
             sc = np.stack(eng.verlet_steps(45))          # crosses re-sorts for n >= 1024
             e1 = eng.compute_forces()                    # a force call right after steps: boxes must be recomputed
+            eng.enqueue_steps(7, sampled=True)
+            sc2 = np.stack(eng.collect_steps(7))
             st = eng.get_state()
-            out.append((e0, sc, e1, np.stack([np.stack(st[k]) for k in ("r", "ru", "v", "a")])))
-    assert out[0][0] == out[1][0] and out[0][2] == out[1][2]
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][3], out[1][3])
+            out.append((e0, sc, e1, np.stack([np.stack(st[k]) for k in ("r", "ru", "v", "a")]), sc2))
+    for other in out[1:]:
+        assert out[0][0] == other[0] and out[0][2] == other[2]
+        assert np.array_equal(out[0][1], other[1]) and np.array_equal(out[0][3], other[3])
+        assert np.array_equal(out[0][4], other[4], equal_nan=True)
 
 
 def test_failed_batch_poisons_the_handle_until_set_state(monkeypatch):
