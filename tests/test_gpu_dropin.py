@@ -56,7 +56,7 @@ def _compare_run(tmp_path, src, n_rows, dt=0.005):
 
 def _compare_statistics_files(out_dir, src):
     """corr_*.dat, corrmean_*.dat and md_final_results.txt of a GPU run against the reference's files.
-    The GPU trajectory stays within ~1e-7 of the reference up to step 1000 (DESIGN 3.3), so sample means
+    The GPU trajectory stays within ~1e-7 of the reference up to step 1000 (DESIGN.md 3.3), so sample means
     agree to 1e-6; fluctuation quantities (std, coefficients, autocovariances) amplify that by the
     ratio value/fluctuation, hence the looser bounds.  (With IDENTICAL samples the files are
     byte-identical: tests/test_stats.py.)"""

@@ -308,7 +308,7 @@ def test_multi_device_handle_emulated_ranks(n, G, monkeypatch):
 @pytest.mark.parametrize("n,G", [(16384, 4), (8192, 8)])
 def test_multi_device_handle_ownership_migration(n, G, monkeypatch):
     """A rank owns an index range, i.e. a fixed set of particles that diffuses out of its slab in a liquid; every
-    LJMD_MULTI_MIGRATE_EVERY steps the multi-device handle deals the particles out again by position (DESIGN.md section 4.1).
+    LJMD_MULTI_MIGRATE_EVERY steps the multi-device handle deals the particles out again by position (DESIGN.md section 4.3).
     With a migration at set_state and before every 20-step segment: the energy series and the final state -- in the CALLER's
     particle order, unwrapped positions included -- against the same run without migration and against the single engine;
     set_unwrapped / set_accel round trips through the owner table; run-to-run bitwise.  The calls come in the production

@@ -1,5 +1,5 @@
 // Does hipGraph replay shorten a chain of small DEPENDENT kernels on this stack?  The MD step of a small system is five
-// kernels of 4-19 us each on one stream.  This probe launches chains of five dependent kernels of ~5 us
+// kernels of 4-19 us each on one stream (MEASUREMENTS.md 3.4).  This probe launches chains of five dependent kernels of ~5 us
 // (each block spins on s_memtime-free arithmetic over a small array) 2000 times: plain stream launches against one
 // captured graph of 20 chains replayed 100 times.  Measurement tool: hipcc --offload-arch=gfx950 -O3 -o graph_probe graph_probe.hip
 #include <hip/hip_runtime.h>

@@ -4,7 +4,7 @@
    <dir>/pmc_hbm_traffic.json   per-kernel HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
    <dir>/pmc_valu.json          per-kernel SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE
                                 per launch and the derived VALU issue fraction (wave-instructions x 4 cycles / (1024 SIMDs x
-                                kernel cycles)) -- the evidence behind "the fp64 pipe is saturated" 
+                                kernel cycles)) -- the evidence behind "the fp64 pipe is saturated" (MEASUREMENTS.md 3.2)
 rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE tallies 64 B per 128-B read request and is
 doubled (MI355X_MICROARCH.md, HBM section)."""
 import csv
