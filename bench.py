@@ -512,7 +512,7 @@ def measure(args) -> None:
             multi_cfg = {
                 "launch_mode": mode,
                 "rccl_ranks_seen": eng.comm_size(),
-                "ownership": f"3-D k-d blocks dealt by position on the devices (ljmd_migrate); migrations so far: {eng.migrations()}",
+                "ownership": f"x-slabs of exactly n/G particles dealt by position on the devices (ljmd_migrate); migrations so far: {eng.migrations()}",
                 "pair_kernel_ms_per_rank": [round(q["pair_ms"], 4) for q in profs],
                 "position_exchange_ms_per_rank": [round(q["pos_exchange_ms"], 4) for q in profs],
                 "force_exchange_ms_per_rank": [round(q["force_exchange_ms"], 4) for q in profs],

@@ -253,9 +253,10 @@ int32_t ljmd_comm_size(const ljmd_t *h);
  * tiles grow and the tile-pair test skips less (-9 % step rate over 10 000 steps at n = 65536 on 8 ranks).  A migration
  * deals all n particles out again BY POSITION: every rank packs ru, v, a and the particle ids of its slots, one all-gather
  * (80 n bytes over xGMI; the positions are in the exchange buffer already) brings everybody's to every rank, every rank
- * computes the same k-d split of the n particles into G near-cubic blocks of exactly n / G (stable radix sorts on
- * identical input: identical result everywhere), keeps block `rank`, re-sorts it into tiles and joins the next position
- * all-gather.  Between two MD steps only (no step half enqueued); pending step records and a snapshot in flight are
+ * computes the same split of the n particles into G parts of exactly n / G (stable radix sorts on identical input:
+ * identical result everywhere; x-slabs by default, near-cubic k-d blocks with LJMD_MIGRATE_DEAL=blocks -- same total work,
+ * but only the translation-symmetric slabs give every rank the same share under the pair kernel's ownership rule), keeps
+ * part `rank`, re-sorts it into tiles and joins the next position all-gather.  Between two MD steps only (no step half enqueued); pending step records and a snapshot in flight are
  * not affected.  No arithmetic of the path changes: the trajectory differs only by summation order.
  *   ljmd_migrate           everything, collectives included: a multi-device handle (ljmd_create_multi; also done
  *                          automatically every LJMD_MULTI_MIGRATE_EVERY steps, default 2000, and at ljmd_set_state), or a

@@ -663,8 +663,16 @@ int migrate_prepare(ljmd_t *h)
 {
     if (h->d_mig) return LJMD_OK;
     const size_t n = (size_t)h->n;
-    // levels of the deal: segments = runs of whole shards, halved (lower half = ceil) until every segment is one shard;
-    // the split axis of a level is the longest remaining extent of the box-wide blocks (ties: x, y, z)
+    // levels of the deal: segments = runs of whole shards, halved (lower half = ceil) until every segment is one shard.
+    // LJMD_MIGRATE_DEAL=slabs (default): every level splits along x -- G slabs.  With rc ~ L/2 every rank needs every
+    // position whatever the shape, so a compact surface buys nothing, while slabs are translation-symmetric in the
+    // periodic box: the pair kernel's ownership rule (row group A owns the groups up to half the ring ahead) then gives
+    // every rank the same work.  =blocks: the longest remaining extent (2 x 2 x 2 near-cubic blocks at G = 8) -- same total
+    // work, but a rank's partners ahead on the ring are face, edge or corner neighbours depending on the rank: measured
+    // 2.50 / 2.28 / 2.05 / 1.85 ms per rank (max / mean = 1.16) against 2.14-2.18 for slabs at n = 262144
+    // (profiles/r03_deal_shapes_per_rank.txt).
+    const char *deal = std::getenv("LJMD_MIGRATE_DEAL");
+    const bool blocks = deal && std::strcmp(deal, "blocks") == 0;
     std::vector<int> offsets, bounds = {0, h->G};
     double ext[3] = {h->L, h->L, h->L};
     while (true) {
@@ -675,8 +683,9 @@ int migrate_prepare(ljmd_t *h)
         h->mig_level_nseg.push_back((int)bounds.size() - 1);
         for (int b : bounds) offsets.push_back(b * h->S);
         int best = 0;
-        for (int ax = 1; ax < 3; ++ax)
-            if (ext[ax] > ext[best] * (1.0 + 1e-9)) best = ax;
+        if (blocks)
+            for (int ax = 1; ax < 3; ++ax)
+                if (ext[ax] > ext[best] * (1.0 + 1e-9)) best = ax;
         h->mig_axis.push_back(best);
         ext[best] *= 0.5;
         std::vector<int> next;

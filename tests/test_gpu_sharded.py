@@ -84,7 +84,7 @@ def _emulated_migration(engines):
                                             (8192, 8, True, True), (8192, 8, True, False)])
 def test_sharded_engines_match_single_engine(n, G, n3, migrate, monkeypatch):
     """migrate: the ownership migration of the one-process-per-GPU form (ljmd_migrate_pack / _deal around the caller's
-    exchange) right after set_state and again after 8 steps -- the ranks then own k-d blocks of particles instead of
+    exchange) right after set_state and again after 8 steps -- the ranks then own slabs dealt by position instead of
     index ranges, identified by ljmd_particle_ids; same bounds against the single engine."""
     monkeypatch.setenv("LJMD_N3_MIN_N", "1" if n3 else "100000000")
     p, r, v = synthetic.make_config(n, seed=5)
@@ -436,7 +436,7 @@ def test_config4_sharded_eight_ranks_n1048576(oracle):
       * accelerations against the CPU oracle's full-matrix rows (the reference's per-pair arithmetic) on 2048-row blocks
         spread over the caller's index range, i.e. over the k-d blocks of all eight ranks: 1e-12 max|a|;
       * the three scalars and the two steps' series against the ONE-rank engine: 1e-12 relative;
-      * Newton 3 across ranks: total force zero; the ranks really own blocks (8 migrated shards, one deal)."""
+      * Newton 3 across ranks: total force zero; the ranks own parts dealt by position (one deal at set_state)."""
     import ctypes
     import os
     n, G = 1048576, 8

@@ -29,23 +29,39 @@ for G in [int(x) for x in os.environ.get("PROBE_G", "1,2,4,8").split(",")]:
         e.force_buffers(True)
         e.set_state(r[0], r[1], r[2], v[0], v[1], v[2])      # every rank k-d sorts its own block
     allgather(engines)                                        # ... and everybody sees the sorted blocks
-    eng = engines[0]
-    eng.forces_partial()
-    for _ in range(2):
-        eng.step_begin(); eng.step_forces(); eng.step_finish()
-    eng.read_partials(2)
-    eng.profile_enable(True)
-    eng.synchronize()
-    t0 = time.perf_counter()
-    steps = 8                                                 # < resort interval: rank 0's block order stays valid
-    for _ in range(steps):
-        eng.step_begin(); eng.step_forces(); eng.step_finish()
-    eng.synchronize()
-    wall = (time.perf_counter() - t0) / steps * 1e3
-    prof = eng.profile_read()
-    if G == 1 or "pair1" not in globals():
-        pair1 = prof["pair_ms"] * G
-    print(f"G={G}: wall {wall:7.3f} ms/step | pair {prof['pair_ms']:7.3f} geometry {prof['geometry_ms']:6.3f} "
-          f"drift(+resort) {prof['drift_ms']:6.3f} reduce+kick {prof['reduce_ms']:6.3f}  -> 1/G of the G=1 pair time would be {pair1 / G:6.3f}", flush=True)
+    if os.environ.get("PROBE_MIGRATE", "0") == "1" and G > 1:
+        # the ownership migration of the one-process-per-GPU form with this script as the collective: k-d blocks by position
+        for e in engines:
+            e.migrate_pack()
+        for e in engines:
+            e.synchronize()
+        bufs = [e.migrate_buffer() for e in engines]
+        for g, (sp, _tot, off, cnt) in enumerate(bufs):
+            for d, dst in enumerate(engines):
+                if d != g:
+                    dst.memcpy(bufs[d][0] + 8 * off, sp + 8 * off, 8 * cnt, 3)
+        for e in engines:
+            e.migrate_deal()
+        allgather(engines)
+    which = [int(x) for x in os.environ.get("PROBE_RANKS", "0").split(",")]
+    for rk in [w for w in which if w < G]:
+      eng = engines[rk]
+      eng.forces_partial()
+      for _ in range(2):
+          eng.step_begin(); eng.step_forces(); eng.step_finish()
+      eng.read_partials(2)
+      eng.profile_enable(True)
+      eng.synchronize()
+      t0 = time.perf_counter()
+      steps = 8                                                 # < resort interval: rank 0's block order stays valid
+      for _ in range(steps):
+          eng.step_begin(); eng.step_forces(); eng.step_finish()
+      eng.synchronize()
+      wall = (time.perf_counter() - t0) / steps * 1e3
+      prof = eng.profile_read()
+      if G == 1 or "pair1" not in globals():
+          pair1 = prof["pair_ms"] * G
+      print(f"G={G} rank {rk}: wall {wall:7.3f} ms/step | pair {prof['pair_ms']:7.3f} geometry {prof['geometry_ms']:6.3f} "
+            f"drift(+resort) {prof['drift_ms']:6.3f} reduce+kick {prof['reduce_ms']:6.3f}  -> 1/G of the G=1 pair time would be {pair1 / G:6.3f}", flush=True)
     for e in engines:
         e.close()
