@@ -209,6 +209,16 @@ int ljmd_verlet_step(int32_t n, double box_length, double dt, double rc,
  */
 int ljmd_rdf_histogram(int32_t n, const double *x, const double *y, const double *z, double box_length,
                        int32_t nbins, double rmax, uint64_t *hist);
+/*
+ * Trajectory analysis, time-origin averages: MSD(lag) = < |ru(t0 + lag) - ru(t0)|^2 > (kind 0, arrays =
+ * unwrapped positions) or VACF(lag) = < v(t0) . v(t0 + lag) > (kind 1, arrays = velocities) over particles and time
+ * origins t0 = 0, origin_stride, ..., exactly as compute_msd_tau_timeorig / compute_vacf_tau_timeorig do
+ * (scripts/md_one_run_analysis.py:404-489): per (origin, lag) the particle mean on the GPU (the reference's per-element
+ * expressions; fixed summation order, equal to numpy's pairwise mean to rounding), the origins added on the host in the
+ * reference's order.  x, y, z: [n_snap][n] host arrays; out: [min(max_lag, n_snap - 1) + 1].  n_snap >= 2.
+ */
+int ljmd_time_origin_average(int32_t kind, int32_t n_snap, int32_t n, const double *x, const double *y, const double *z,
+                             int32_t max_lag, int32_t origin_stride, double *out);
 /* The stateless entry points keep one cached engine (device LJMD_DEVICE, default 0).  ljmd_verlet_step
  * remembers the nine arrays it handed back; when the next call passes the same bytes again (the reference's
  * loop only reads them between steps) the resident state is stepped directly -- no upload, no spatial re-sort,

@@ -75,6 +75,8 @@ PROTOTYPES = {
     "ljmd_stateless_reset": (None, []),
     "ljmd_rdf_histogram": (C.c_int, [C.c_int32, c_double_p, c_double_p, c_double_p, C.c_double, C.c_int32,
                                      C.c_double, C.POINTER(C.c_uint64)]),
+    "ljmd_time_origin_average": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int32,
+                                           C.c_int32, c_double_p]),
     "ljmd_shard_range": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p]),
     "ljmd_exchange_buffer": (C.c_void_p, [C.c_void_p, c_int64_p, c_int64_p, c_int64_p]),
     "ljmd_device_ptr": (C.c_void_p, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -6,7 +6,8 @@ The O(n^2) pair pass of the RDF runs on the GPU (`ljmd_rdf_histogram`, integer h
 bit-exact); with `subsample=True` the reference's sub-sampling (<= 200 snapshots, <= 800
 particles, chosen with np.linspace) is applied first, so the result equals the reference's
 for the same input; `subsample=False` uses every particle of every snapshot -- the case the
-reference cannot afford in numpy.  MSD / VACF are O(n_snap^2 n) streaming sums on the host.
+reference cannot afford in numpy.  MSD / VACF: `time_origin_average_gpu` (the O(n_snap^2 n) sums in a HIP kernel) beside
+the numpy mirror of the reference's functions (bit-identical to the reference module; the CPU tests' checker).
 """
 from __future__ import annotations
 
@@ -58,6 +59,21 @@ def compute_rdf(rx: np.ndarray, ry: np.ndarray, rz: np.ndarray, L: float, nbins:
     mask = norm > 0
     g[mask] = hist[mask] / norm[mask]
     return r_centers, g
+
+
+def time_origin_average_gpu(kind: int, x, y, z, max_lag=None, origin_stride: int = 1) -> np.ndarray:
+    """MSD (kind 0: unwrapped positions) / VACF (kind 1: velocities) on the GPU (`ljmd_time_origin_average`): the
+    O(n_snap^2 n) particle means per (origin, lag) in a HIP kernel, the origins added on the host in the reference's order.
+    Equal to compute_msd_tau_timeorig / compute_vacf_tau_timeorig below to rounding (numpy's mean is a pairwise sum)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z)]
+    n_snap, n = arrs[0].shape
+    if n_snap < 2:
+        return compute_msd_tau_timeorig(*arrs) if kind == 0 else compute_vacf_tau_timeorig(*arrs)
+    max_lag = n_snap - 1 if max_lag is None else int(min(max_lag, n_snap - 1))
+    out = np.empty(max_lag + 1, dtype=np.float64)
+    _lib.check(_lib.load().ljmd_time_origin_average(kind, n_snap, n, *[a.ctypes.data_as(c_double_p) for a in arrs], max_lag,
+                                                    max(1, int(origin_stride)), out.ctypes.data_as(c_double_p)))
+    return out
 
 
 def _time_origin_average(series, max_lag, origin_stride, term):

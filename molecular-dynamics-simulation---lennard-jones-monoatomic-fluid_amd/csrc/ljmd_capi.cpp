@@ -66,6 +66,7 @@ GeometryArgs geometry_args(ljmd_t *h)
     a.rc2_skin = h->rc2 * (1.0 + 1e-10);
     a.mask_far = h->d_mask_far;       // NULL unless mixed precision
     a.rsplit2 = h->r_split * h->r_split;
+    a.pertile_images = env_int("LJMD_N3_PERTILE", 1) != 0 ? 1 : 0;
     return a;
 }
 
@@ -1975,6 +1976,57 @@ int ljmd_rdf_histogram(int32_t n, const double *x, const double *y, const double
     const int rc_ = body();
     (void)hipFree(d);
     (void)hipFree(dh);
+    return rc_;
+}
+
+int ljmd_time_origin_average(int32_t kind, int32_t n_snap, int32_t n, const double *x, const double *y, const double *z,
+                             int32_t max_lag, int32_t origin_stride, double *out)
+{
+    if ((kind != 0 && kind != 1) || n_snap < 2 || n < 1 || !x || !y || !z || !out || max_lag < 0 || origin_stride < 1)
+        return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_time_origin_average: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, LJMD_ERR_NO_DEVICE, "ljmd_time_origin_average: no HIP device available (this library has no CPU path)");
+    LJMD_HIP(nullptr, hipSetDevice(env_int("LJMD_DEVICE", 0)));
+    max_lag = std::min(max_lag, n_snap - 1);
+    const int n_origins = (n_snap - 1 + origin_stride - 1) / origin_stride;       // t0 = 0, stride, ... < n_snap - 1
+    const size_t bytes = (size_t)n_snap * n * sizeof(double), nterm = (size_t)n_origins * (max_lag + 1);
+    double *d = nullptr, *dt = nullptr;
+    auto body = [&]() -> int {
+        LJMD_HIP(nullptr, hipMalloc(&d, 3 * bytes));
+        LJMD_HIP(nullptr, hipMalloc(&dt, nterm * sizeof(double)));
+        LJMD_HIP(nullptr, hipMemcpy(d, x, bytes, hipMemcpyHostToDevice));
+        LJMD_HIP(nullptr, hipMemcpy(d + (size_t)n_snap * n, y, bytes, hipMemcpyHostToDevice));
+        LJMD_HIP(nullptr, hipMemcpy(d + 2 * (size_t)n_snap * n, z, bytes, hipMemcpyHostToDevice));
+        TimeOriginArgs a;
+        a.x = d;
+        a.y = d + (size_t)n_snap * n;
+        a.z = d + 2 * (size_t)n_snap * n;
+        a.term = dt;
+        a.n_snap = n_snap;
+        a.n = n;
+        a.max_lag = max_lag;
+        a.origin_stride = origin_stride;
+        LJMD_HIP(nullptr, launch_time_origin(a, kind == 1, n_origins, nullptr));
+        std::vector<double> term(nterm);
+        LJMD_HIP(nullptr, hipMemcpy(term.data(), dt, nterm * sizeof(double), hipMemcpyDeviceToHost));
+        // the reference's accumulation: for t0 ascending, acc[:L + 1] += term(t0, :), counts[:L + 1] += 1, then acc / counts
+        std::vector<double> acc(max_lag + 1, 0.0);
+        std::vector<long> counts(max_lag + 1, 0);
+        for (int k = 0; k < n_origins; ++k) {
+            const int t0 = k * origin_stride, L = std::min(max_lag, (n_snap - 1) - t0);
+            if (L <= 0) continue;
+            for (int lag = 0; lag <= L; ++lag) {
+                acc[lag] += term[(size_t)k * (max_lag + 1) + lag];
+                counts[lag] += 1;
+            }
+        }
+        for (int lag = 0; lag <= max_lag; ++lag) out[lag] = counts[lag] > 0 ? acc[lag] / (double)counts[lag] : 0.0;
+        return LJMD_OK;
+    };
+    const int rc_ = body();
+    (void)hipFree(d);
+    (void)hipFree(dt);
     return rc_;
 }
 

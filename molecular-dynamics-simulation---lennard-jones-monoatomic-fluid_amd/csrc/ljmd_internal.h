@@ -125,6 +125,7 @@ struct GeometryArgs {
     int RT;                 // tiles per Newton-3 row group (same-group pairs always count as NEAR)
     double L, invL, rc2_skin;   // rc^2 * (1 + 1e-10): skip only when provably outside
     double rsplit2;         // r_split^2
+    int pertile_images;     // tile_class: row tiles may take their own periodic image on a single general axis (LJMD_N3_PERTILE)
 };
 
 struct RdfArgs {
@@ -133,6 +134,12 @@ struct RdfArgs {
     int n, nbins, chunk;           // chunk = j per grid.y slice
     double L, rmax, dr;
     double invL, inv_dr;           // 1 / L, 1 / dr: fast paths of the two divisions (exact path kept for near-ties)
+};
+
+struct TimeOriginArgs {
+    const double *x, *y, *z;       // [n_snap][n] unwrapped positions (MSD) or velocities (VACF)
+    double *term;                  // [n_origins][max_lag + 1] particle mean per (origin, lag); entries beyond an origin's reach untouched
+    int n_snap, n, max_lag, origin_stride;
 };
 
 struct SortArgs {
@@ -161,6 +168,7 @@ hipError_t launch_finalize(const FinalizeArgs &a, double *fold_scratch /* [2 * k
 hipError_t launch_tile_tail(const ReduceArgs &ra, const IntegrateArgs &a, const FinalizeArgs &f, bool kick, bool drift,
                             hipStream_t s);
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
+hipError_t launch_time_origin(const TimeOriginArgs &a, bool vacf, int n_origins, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s);
 hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc,

@@ -906,7 +906,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
                     GeometryArgs ga;
                     ga.pos = nullptr; ga.bbox = const_cast<double *>(a.bbox); ga.pos_tc = nullptr; ga.mask = nullptr; ga.mask_far = nullptr;
                     ga.P = a.P; ga.G = a.G; ga.rank = a.rank; ga.TB = a.TB; ga.T = a.T; ga.W = a.W; ga.RT = 1;
-                    ga.L = a.L; ga.invL = a.invL; ga.rc2_skin = a.rc2_skin; ga.rsplit2 = 0.0;
+                    ga.L = a.L; ga.invL = a.invL; ga.rc2_skin = a.rc2_skin; ga.rsplit2 = 0.0; ga.pertile_images = 0;
                     unsigned dsc = 0;
                     (void)tile_class(ga, a.invL, a.rc2, a.S, Al, c, dsc, nullptr, nullptr);
                     desc = (unsigned)__builtin_amdgcn_readfirstlane((int)dsc);
@@ -934,6 +934,16 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             const bool have = mb != 0;
             double jx = 0.0, jy = 0.0, jz = 0.0;
             bool stored = false;
+            const bool pertile = have && ((desc >> 21) & 1u);
+            if (pertile) {
+                // per-tile periodic images on one axis (tile_class): the lane's row particles of this pass
+                const int axis = (int)((desc >> 22) & 3u);
+#pragma unroll
+                for (int k = 0; k < RT; ++k) {
+                    const double sh = (double)((int)((desc >> (24 + 2 * k)) & 3u) - 1) * a.L;
+                    if (axis == 0) xi[k] -= sh; else if (axis == 1) yi[k] -= sh; else zi[k] -= sh;
+                }
+            }
             if (have) {
                 // two-level energy sums: a pass (<= 256 terms per lane) sums into its own pair, which is added to the
                 // work item's running pair once -- the rounding error of a lane's sum no longer grows with the number of
@@ -950,6 +960,14 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
                     n3_tile_pass<RT, W, ENERGY>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, parked, jx, jy, jz, p12, p6);
                 s12 += p12;
                 s6 += p6;
+            }
+            if (pertile) {                                     // the lane's row particles as they are, bit for bit
+                const int axis = (int)((desc >> 22) & 3u);
+#pragma unroll
+                for (int k = 0; k < RT; ++k) {
+                    const double x0 = own[(size_t)axis * P + (size_t)(RT * Al + k) * kTile + lane];
+                    if (axis == 0) xi[k] = x0; else if (axis == 1) yi[k] = x0; else zi[k] = x0;
+                }
             }
             if constexpr (W == 1) {
                 if (have && !stored) {
@@ -1312,6 +1330,8 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
 //   bit   10     FULL: no padding slot in the row group or the column tile
 //   bits 11..19  common image per axis, n + 2 in 3 bits each (shift = n L)
 //   bit   20     CLUSTER: the pass runs cluster by cluster (n3_cluster_pass) with the direction / thresholds in desc2
+//   bit   21     PERTILE: the row tiles are shifted by whole box lengths on axis (bits 22-23) for this pass, tile k by
+//                (bits 24 + 2k .. 25 + 2k) - 1; the column tile's common image on that axis is the first active tile's
 // Same expressions as the former in-kernel classification; the row group's box is the union of its tiles' exact
 // boxes (= min / max over its 256 particles).
 // ---------------------------------------------------------------------------
@@ -1362,14 +1382,42 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
     const bool uy = uniform_image(lo[1], hi[1], a.L, invL, sy);
     const bool uz = uniform_image(lo[2], hi[2], a.L, invL, sz);
     int nu = (ux ? 0 : 1) | (uy ? 0 : 2) | (uz ? 0 : 4);
-    const double fx = fmax(fabs(lo[0] - sx), fabs(hi[0] - sx)), fy = fmax(fabs(lo[1] - sy), fabs(hi[1] - sy)),
-                 fz = fmax(fabs(lo[2] - sz), fabs(hi[2] - sz));
+    // ONE axis without a common image for the row GROUP (its box, 4 tiles, straddles +-L/2 against the column tile): the
+    // row TILES, half as wide, mostly have one each.  Then the column tile takes the image of the first active row tile
+    // and the other row tiles are shifted by -1 / 0 / +1 box lengths for this pass (pair_n3_kernel: shift_rows): the pass
+    // runs the plain loop (3 instructions per pair less than the general minimum image) and may run cluster by cluster.
+    // 19-23 % of the passes of the liquid have a general axis; about half of them go this way.
+    int pq = -1;                                              // the axis, -1 = none
+    int pm[4] = {0, 0, 0, 0};                                  // per row tile: image relative to the first active tile's
+    if (a.pertile_images && !desc_far && RT > 1 && mb != 0 && (nu == 1 || nu == 2 || nu == 4)) {
+        const int q = nu == 1 ? 0 : nu == 2 ? 1 : 2;
+        int nk[4] = {0, 0, 0, 0}, nbase = 0;
+        bool ok = true, have = false;
+        for (int k = 0; k < RT && ok; ++k) {
+            if (!((mb >> k) & 1u)) continue;
+            const double *bb = a.bbox + (size_t)(a.rank * a.TB + RT * Al + k) * kBoxStride;
+            double sk = 0.0;
+            ok = uniform_image(bb[q] - cbx[3 + q], bb[3 + q] - cbx[q], a.L, invL, sk);
+            nk[k] = (int)__builtin_rint(sk * invL);
+            if (ok && !have) { nbase = nk[k]; have = true; }
+            ok = ok && nk[k] - nbase >= -1 && nk[k] - nbase <= 1;
+        }
+        if (ok && have) {
+            pq = q;
+            for (int k = 0; k < RT; ++k) pm[k] = ((mb >> k) & 1u) ? nk[k] - nbase : 0;
+            const double sb = (double)nbase * a.L;
+            if (q == 0) sx = sb; else if (q == 1) sy = sb; else sz = sb;
+            nu = 0;                                             // a common image on every axis now
+        }
+    }
+    // box of row tile k on axis q as the pass sees it
+    auto row_lo = [&](const double *bb, int k, int q) { return bb[q] - (q == pq ? (double)pm[k] * a.L : 0.0); };
+    auto row_hi = [&](const double *bb, int k, int q) { return bb[3 + q] - (q == pq ? (double)pm[k] * a.L : 0.0); };
     const bool group_full = (RT * Al + RT) * kTile <= S;
     const bool full = group_full && ((c - (a.G == 1 ? 0 : c / a.TB) * a.TB) + 1) * kTile <= S;
     // INNER: every pair of every ACTIVE row tile provably inside the cutoff (farthest corners of the exact tile boxes;
     // the group's box, the union, proves less: 33 % instead of 44 % of the passes of the bench configuration)
     bool inner = nu == 0 && full && mb != 0;
-    (void)fx; (void)fy; (void)fz;
     for (int k = 0; k < RT && inner; ++k) {
         if (!((mb >> k) & 1u)) continue;
         const double *bb = a.bbox + (size_t)(a.rank * a.TB + RT * Al + k) * kBoxStride;
@@ -1377,7 +1425,7 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
         double far2 = 0.0;
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const double f = fmax(fabs((bb[q] - cbx[3 + q]) - sh[q]), fabs((bb[3 + q] - cbx[q]) - sh[q]));
+            const double f = fmax(fabs((row_lo(bb, k, q) - cbx[3 + q]) - sh[q]), fabs((row_hi(bb, k, q) - cbx[q]) - sh[q]));
             far2 += f * f;
         }
         inner = far2 < rc2 * (1.0 - 1e-10);
@@ -1397,6 +1445,10 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
     const int nx = (int)__builtin_rint(sx * invL), ny = (int)__builtin_rint(sy * invL), nzs = (int)__builtin_rint(sz * invL);
     unsigned cls = ((unsigned)nu << 4) | ((unsigned)inner << 9) | ((unsigned)full << 10) |
                    ((unsigned)(nx + 2) << 11) | ((unsigned)(ny + 2) << 14) | ((unsigned)(nzs + 2) << 17);
+    if (pq >= 0) {                                            // bit 21: per-tile images; 22-23: the axis; 24..31: image + 1 per row tile
+        cls |= (1u << 21) | ((unsigned)pq << 22);
+        for (int k = 0; k < 4; ++k) cls |= (unsigned)(pm[k] + 1) << (24 + 2 * k);
+    }
     // Cluster pass (pair_n3_kernel: n3_cluster_pass): a pass at the cutoff boundary with a common image on every axis, no
     // padding slot, not inside the diagonal group.  desc2 = the unit direction n from the row group to the (shifted)
     // column tile, and per row tile k the threshold  thr_k = max over the tile's box of n.x  +  rc  +  margin:
@@ -1406,6 +1458,15 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
         (nu == 8 || nu == 16 || nu == 17 || nu == 18 || nu == 0)) {
         double dir[3], len2 = 0.0;
         const double sh[3] = {sx, sy, sz};
+        if (pq >= 0) {                                         // the group's box as the pass sees it: its tiles shifted
+            glo[pq] = __builtin_inf();
+            ghi[pq] = -__builtin_inf();
+            for (int k = 0; k < RT; ++k) {
+                const double *bb = a.bbox + (size_t)(a.rank * a.TB + RT * Al + k) * kBoxStride;
+                glo[pq] = fmin(glo[pq], row_lo(bb, k, pq));
+                ghi[pq] = fmax(ghi[pq], row_hi(bb, k, pq));
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             dir[q] = (0.5 * (cbx[q] + cbx[3 + q]) + sh[q]) - 0.5 * (glo[q] + ghi[q]);
@@ -1428,7 +1489,7 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
                     const double *bb = a.bbox + (size_t)(a.rank * a.TB + RT * Al + k) * kBoxStride;
                     double supp = 0.0;
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) supp += fmax((double)nf[q] * bb[q], (double)nf[q] * bb[3 + q]);
+                    for (int q = 0; q < 3; ++q) supp += fmax((double)nf[q] * row_lo(bb, k, q), (double)nf[q] * row_hi(bb, k, q));
                     o[3 + k] = (float)(supp + rc + 1e-3);
                 }
                 for (int k = RT; k < 4; ++k) o[3 + k] = 0.0f;
@@ -1948,6 +2009,34 @@ __global__ __launch_bounds__(kBlock) void rdf_histogram_kernel(RdfArgs a)
         if (lhist[b]) atomicAdd(&a.hist[b], (unsigned long long)lhist[b]);
 }
 
+// ===========================================================================
+// Trajectory analysis, time-origin averages: the per-(origin, lag) particle means of the reference's
+// compute_msd_tau_timeorig / compute_vacf_tau_timeorig (scripts/md_one_run_analysis.py:404-489):
+//   MSD :  mean_i |ru_i(t0 + lag) - ru_i(t0)|^2        VACF:  mean_i v_i(t0) . v_i(t0 + lag)
+// One block per (lag, origin); per element the reference's numpy expression (dx*dx + dy*dy + dz*dz with separate
+// roundings; x*x0 + y*y0 + z*z0), summed over the particles in a fixed order (the reference's np.mean is a pairwise
+// sum: the two agree to rounding, ~1e-16 relative, not bit for bit).  The host adds the origins in the reference's order.
+// ===========================================================================
+template <bool VACF>
+__global__ __launch_bounds__(kBlock) void time_origin_kernel(TimeOriginArgs a)
+{
+    __shared__ double red[kWavesPerBlock];
+    const int lag = blockIdx.x, t0 = blockIdx.y * a.origin_stride;
+    if (t0 + lag >= a.n_snap || lag > min(a.max_lag, a.n_snap - 1 - t0)) return;      // (whole block: uniform)
+    const size_t o0 = (size_t)t0 * a.n, o1 = (size_t)(t0 + lag) * a.n;
+    double s[1] = {0.0};
+    for (int i = threadIdx.x; i < a.n; i += kBlock) {
+        if constexpr (VACF) {
+            s[0] += a.x[o1 + i] * a.x[o0 + i] + a.y[o1 + i] * a.y[o0 + i] + a.z[o1 + i] * a.z[o0 + i];
+        } else {
+            const double dx = a.x[o1 + i] - a.x[o0 + i], dy = a.y[o1 + i] - a.y[o0 + i], dz = a.z[o1 + i] - a.z[o0 + i];
+            s[0] += dx * dx + dy * dy + dz * dz;
+        }
+    }
+    block_sum<1>(s, red);
+    if (threadIdx.x == 0) a.term[(size_t)blockIdx.y * (a.max_lag + 1) + lag] = s[0] / (double)a.n;
+}
+
 // ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
@@ -2079,6 +2168,16 @@ hipError_t launch_sum_blocks(const double *blocks, double *out, int G, int len, 
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(kinetic_fused_kernel, dim3((a.rows + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_time_origin(const TimeOriginArgs &a, bool vacf, int n_origins, hipStream_t s)
+{
+    const dim3 grid(a.max_lag + 1, n_origins);
+    if (vacf)
+        hipLaunchKernelGGL(time_origin_kernel<true>, grid, dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL(time_origin_kernel<false>, grid, dim3(kBlock), 0, s, a);
     return hipGetLastError();
 }
 

@@ -91,3 +91,30 @@ def test_rdf_gpu_exact_on_ties_and_bin_edges(oracle, L, rmax_frac, nbins):
     analysis.rdf_histogram(x, y, z, L, nbins, rmax_frac * L, h_gpu)
     oracle.rdf_histogram_np(x.copy(), y.copy(), z.copy(), L, nbins, rmax_frac * L, h_ora)
     assert np.array_equal(h_gpu, h_ora) and h_gpu.sum() > 0
+
+
+@pytest.mark.gpu
+def test_msd_vacf_gpu_match_reference_golden_and_numpy_at_size(golden):
+    """MSD / VACF on the GPU (ljmd_time_origin_average) against the reference module's own output on the reference's
+    rva.dat (tests/golden/analysis_n108.npz: 90 snapshots of N = 108) -- equal to rounding, 1e-13 relative: the
+    reference's np.mean sums pairwise, the kernel in a fixed strided order -- with max_lag / origin_stride as the
+    reference passes them, and against the numpy mirror on a synthetic trajectory of 8192 particles x 24 snapshots."""
+    g = golden("analysis_n108")
+    _, snaps = io_formats.read_rva(GOLDEN / "ref_run_n108_oi100" / "rva.dat")
+    ru, v = snaps[:, 1], snaps[:, 2]
+
+    def close(a, b):
+        return a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-13 * max(np.max(np.abs(b)), 1e-300)
+
+    assert close(analysis.time_origin_average_gpu(0, ru[:, 0], ru[:, 1], ru[:, 2]), g["msd"])
+    assert close(analysis.time_origin_average_gpu(1, v[:, 0], v[:, 1], v[:, 2]), g["vacf"])
+    assert close(analysis.time_origin_average_gpu(0, ru[:, 0], ru[:, 1], ru[:, 2], max_lag=4, origin_stride=2),
+                 g["msd_lag4_stride2"])
+    rng = np.random.Generator(np.random.PCG64(11))
+    walk = np.cumsum(rng.normal(0.0, 0.05, size=(3, 24, 8192)), axis=1) + rng.uniform(0, 20, size=(3, 1, 8192))
+    vel = rng.normal(0.0, 1.0, size=(3, 24, 8192))
+    for stride, lag in ((1, None), (3, 10)):
+        assert close(analysis.time_origin_average_gpu(0, *walk, max_lag=lag, origin_stride=stride),
+                     analysis.compute_msd_tau_timeorig(*walk, max_lag=lag, origin_stride=stride))
+        assert close(analysis.time_origin_average_gpu(1, *vel, max_lag=lag, origin_stride=stride),
+                     analysis.compute_vacf_tau_timeorig(*vel, max_lag=lag, origin_stride=stride))

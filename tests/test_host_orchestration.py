@@ -154,6 +154,12 @@ dp = C.POINTER(C.c_double)
 assert lib.ljmd_rdf_histogram(500, x[0].ctypes.data_as(dp), x[1].ctypes.data_as(dp), x[2].ctypes.data_as(dp), 10.0, 64,
                               4.0, hist) == 0
 
+# time-origin averages (MSD / VACF)
+from ljmd_amd import analysis
+tr = np.random.default_rng(2).normal(size=(3, 7, 300))
+assert analysis.time_origin_average_gpu(0, *tr, max_lag=4, origin_stride=2).shape == (5,)
+assert analysis.time_origin_average_gpu(1, *tr).shape == (7,)
+
 # a failure half-way through a batch poisons the handle; set_state revives it
 os.environ["LJMD_INJECT_FAILURE_AT_STEP"] = "2"
 p, r, v = synthetic.make_config(4096, seed=13)
