@@ -781,7 +781,7 @@ int migrate_rebase(ljmd_t *h)
 // ---------------------------------------------------------------------------
 extern "C" {
 
-const char *ljmd_version(void) { return "ljmd 0.5.0 gfx950"; }
+const char *ljmd_version(void) { return "ljmd 0.6.0 gfx950"; }
 
 int32_t ljmd_device_count(void)
 {
