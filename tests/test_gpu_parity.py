@@ -110,6 +110,39 @@ def test_production_kernel_configuration_vs_oracle_n32768(oracle):
     assert np.abs(a - a_o).max() <= REL_ACCEL * np.abs(a_o).max()
 
 
+@pytest.mark.parametrize("knobs", [{}, {"LJMD_N3_CLUSTERS": "0"}, {"LJMD_N3_PERTILE": "0"}])
+def test_cluster_passes_and_per_tile_images_vs_oracle_n32768(oracle, knobs, monkeypatch):
+    """The boundary machinery of the production kernel at a size the oracle checks on EVERY particle: 4-tile row groups
+    forced at n = 32768 (they are the default from 65536), so that cluster passes (column tile sorted along the
+    row->column direction, (row tile, cluster) skips by projection) and per-tile periodic images (row tiles shifted by
+    +-L for a pass) are on; 12 steps WITHOUT re-sort from a start with lattice planes on the box faces, so that tiles
+    straddle faces and the image logic is exercised, then forces and scalars at the engine's own positions.  A wrongly
+    skipped pair inside the cutoff would show as an error of 1e-3; the bounds are the usual 1e-12.  Knobs: both
+    features on (default), each one off (the answers must agree with the oracle either way)."""
+    monkeypatch.setenv("LJMD_N3_ROW_TILES", "4")
+    monkeypatch.setenv("LJMD_RESORT_EVERY", "1000")
+    for k, val in knobs.items():
+        monkeypatch.setenv(k, val)
+    n = 32768
+    p, r, v = synthetic.make_config(n, seed=5)
+    L = p.box_length
+    r = (r + 0.5 * L / 32.0) % L
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        e0, d0, dd0 = eng.compute_forces()
+        a0 = np.stack(eng.get_state(("a",))["a"])
+        e, k_, d, dd = eng.verlet_steps(12)
+        st = eng.get_state(("r", "a"))
+    eo, do, ddo, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    assert rel(e0, eo) <= 1e-12 and rel(d0, do) <= 1e-12 and rel(dd0, ddo) <= 1e-12
+    assert np.abs(a0 - np.stack([ax, ay, az])).max() <= REL_ACCEL * np.abs(ax).max()
+    rr, a = np.stack(st["r"]), np.stack(st["a"])
+    eo, do, ddo, ax, ay, az = oracle.compute_forces(po, rr[0].copy(), rr[1].copy(), rr[2].copy())
+    assert rel(e[-1], eo) <= 1e-12 and rel(d[-1], do) <= 1e-12 and rel(dd[-1], ddo) <= 1e-12
+    assert np.abs(a - np.stack([ax, ay, az])).max() <= REL_ACCEL * np.abs(ax).max()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_tiles_that_straddle_a_box_face_vs_oracle_n32768(oracle, mode, monkeypatch):
     """Between two re-sorts particles cross the faces of the box and reappear at the other end of the wrapped interval
