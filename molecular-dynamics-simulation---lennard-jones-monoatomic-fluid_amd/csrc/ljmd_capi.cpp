@@ -92,7 +92,8 @@ N3Args n3_args(ljmd_t *h)
     a.NG = h->NG;
     a.NGo = h->NGo;
     a.Dmax = h->Dmax;
-    a.Q = h->Q;
+    a.CS = h->CS;
+    a.by_group = h->j_by_group;
     a.dchunk = h->dchunk;
     a.xcd_remap = 0;
     a.inline_class = (h->fuse_tail && h->rt == 1 && h->wg_waves == 1) ? 1 : 0;
@@ -142,12 +143,8 @@ ReduceArgs reduce_args(ljmd_t *h, int nslab, bool n3)
     a.G = h->G;
     a.rank = h->rank;
     a.TB = h->TB;
-    a.NG = h->NG;
-    a.NGo = h->NGo;
-    a.Dmax = h->Dmax;
-    a.Q = h->Q;
-    a.WG = h->wg_waves;
-    a.Q2 = h->Q2;
+    a.CS = h->CS;
+    a.CS2 = h->CS2;
     a.RT = h->rt;
     return a;
 }
@@ -307,7 +304,7 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
                 fa.slab_j = h->d_slab_j2;
                 fa.flag_j = h->d_flag_j2;
                 fa.desc = h->d_desc_far;
-                fa.Q = h->Q2;
+                fa.CS = h->CS2;
                 fa.xcd_remap = (h->xcd_remap > 0 && (int)fgrid.x >= h->xcd_min_groups && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
                 LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, h->stream));
@@ -936,13 +933,15 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         int wg = env_int("LJMD_N3_WG_WAVES", 0);
         if (wg != 1 && wg != 2 && wg != 4) {
             const double budget = 1e9 * std::max(1, env_int("LJMD_SLAB_BUDGET_GB", 64));
-            const double full = (double)h->NGo * (h->Dmax + 1) * rt * 3.0 * kTile * sizeof(double);
+            const double full = (double)h->T * (h->G > 1 ? h->NGo : h->Dmax + 1) * 3.0 * kTile * sizeof(double);   // slab_j at wg = 1
             wg = full <= budget ? 1 : full <= 2.0 * budget ? 2 : 4;
         }
         if (rt != kRowTiles || h->NGo < 16 * wg) wg = 1;
         h->wg_waves = wg;
-        h->Q = (h->Dmax + wg) * rt;
-        h->Q2 = (h->Dmax + 1) * rt;
+        // slab_j: the blocks of a column tile lie together (N3Args::slab_j)
+        h->j_by_group = (h->G > 1 || h->NG % wg != 0) ? 1 : 0;
+        h->CS = h->j_by_group ? (h->NGo + wg - 1) / wg : (h->Dmax + wg - 1) / wg + 1;
+        h->CS2 = h->G > 1 ? h->NGo : h->Dmax + 1;              // far pass: one wave per workgroup
         const int n3_min = env_int("LJMD_N3_MIN_N", 4096);
         // (rc within 1e-9 of L/2 -- the reference accepts rc_over_L up to 0.5 and rejects only rc >= L/2 -- takes the exact
         //  generic kernel, which has no Newton-3 form: a multi-rank run then needs no force exchange at all, and every
@@ -992,7 +991,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_slab, P3 * nslab_max));
         LJMD_HIP(h, hipMalloc(&h->d_wg_part, 2 * (size_t)n_wg_max * sizeof(double)));
         if (h->use_n3) {
-            const size_t n_blk = (size_t)((h->NGo + h->wg_waves - 1) / h->wg_waves) * h->Q;
+            const size_t n_blk = (size_t)h->T * h->CS;
             LJMD_HIP(h, hipMalloc(&h->d_slab_j, n_blk * 3 * kTile * sizeof(double)));
             LJMD_HIP(h, hipMalloc(&h->d_flag_j, n_blk));
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, n_blk, h->stream));
@@ -1005,9 +1004,10 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         if (mixed) {
             LJMD_HIP(h, hipMalloc(&h->d_mask_far, (size_t)h->TB * h->W * sizeof(uint64_t)));
             LJMD_HIP(h, hipMalloc(&h->d_desc_far, (size_t)h->NGo * h->T * sizeof(unsigned)));
-            LJMD_HIP(h, hipMalloc(&h->d_slab_j2, (size_t)h->NGo * h->Q2 * 3 * kTile * sizeof(double)));
-            LJMD_HIP(h, hipMalloc(&h->d_flag_j2, (size_t)h->NGo * h->Q2));
-            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j2, 0, (size_t)h->NGo * h->Q2, h->stream));
+            const size_t n_blk2 = (size_t)h->T * h->CS2;
+            LJMD_HIP(h, hipMalloc(&h->d_slab_j2, n_blk2 * 3 * kTile * sizeof(double)));
+            LJMD_HIP(h, hipMalloc(&h->d_flag_j2, n_blk2));
+            LJMD_HIP(h, hipMemsetAsync(h->d_flag_j2, 0, n_blk2, h->stream));
         }
         LJMD_HIP(h, hipMalloc(&h->d_fpart, P3 * (needs_force_exchange(h) ? h->G : 1)));
         if (needs_force_exchange(h)) LJMD_HIP(h, hipMalloc(&h->d_frecv, P3));

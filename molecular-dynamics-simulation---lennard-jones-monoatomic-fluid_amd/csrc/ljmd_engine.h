@@ -139,8 +139,8 @@ struct ljmd {
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
     int wg_waves = 1;                 // LJMD_N3_WG_WAVES: row groups (waves) per pair-kernel workgroup (1, 2, 4)
-    int Q2 = 0;                       // column tiles per row group of the fp32 far pass (one wave per workgroup)
-    int NG = 0, NGo = 0, Dmax = 0, Q = 0, nslab_n = 1, dchunk = 0;
+    int CS = 0, CS2 = 0, j_by_group = 0;   // slab_j / slab_j2: blocks per column tile, block numbering (N3Args::slab_j)
+    int NG = 0, NGo = 0, Dmax = 0, nslab_n = 1, dchunk = 0;
     int rt = kRowTiles;               // tiles per row group (LJMD_N3_ROW_TILES; auto: 4, or 2 / 1 for small systems)
     double *d_slab_j = nullptr;
     unsigned char *d_flag_j = nullptr;

@@ -56,12 +56,16 @@ struct N3Args {
     const unsigned *desc;   // [NGo][T] pass descriptors of tile_class_kernel (row-tile mask bits, loop variant, images)
     const float *desc2;     // [NGo][T][8] cluster passes: direction n (3), thresholds of the RT row tiles (4), pad; or NULL
     double *slab_i;         // [nchunk][3][P] partial accelerations of the owned rows (row side)
-    double *slab_j;         // [ceil(NGo/WG)][Q][3][64] column-side partial accelerations: one block per (workgroup of WG
-                            // consecutive row groups, column tile), Q = (Dmax + WG) * RT column tiles per workgroup
-    unsigned char *flag_j;  // [ceil(NGo/WG)][Q] 1 = slab_j block written this step
+    double *slab_j;         // [T][CS][3][64] column-side partial accelerations: one block per (column tile, workgroup of WG
+                            // consecutive row groups); the CS blocks of a column tile lie together, so that the reduction
+                            // streams them.  Block j of column tile c: by_group ? the workgroup's index : e / WG, with e =
+                            // the column group's offset from the workgroup's first row group (single rank, WG | NG: one
+                            // workgroup per value, CS = (Dmax + WG - 1) / WG + 1)
+    unsigned char *flag_j;  // [T][CS] 1 = slab_j block written this step
     double *wg_part;        // [n workgroups][2]
     int S, P, G, rank, TB, T, W;   // S = real particles per rank (slots S..P-1 are padding)
-    int NG, NGo, Dmax, Q;   // row groups in total / owned by this rank (NGo = TB / RT, NG = G * NGo), Q = (Dmax+1)*RT
+    int NG, NGo, Dmax;      // row groups in total / owned by this rank (NGo = TB / RT, NG = G * NGo)
+    int CS, by_group;       // slab_j layout (above)
     int RT;                 // tiles per row group: 4 for large systems, 1 or 2 to give small ones enough work items
     int dchunk;             // offsets d per grid.y slice
     int energy;             // 0: forces only -- the energy sums are not accumulated and the workgroup partials are NaN
@@ -94,11 +98,11 @@ struct ReduceArgs {
     const double *slab;     // row side [nslab][3][P]
     const double *slab_j;   // column side (Newton-3) or NULL
     const unsigned char *flag_j;
-    const double *slab_j2;  // second column-side set (fp32 far pass of the mixed-precision mode: [NGo][Q2] blocks) or NULL
+    const double *slab_j2;  // second column-side set (fp32 far pass of the mixed-precision mode: [T][CS2] blocks) or NULL
     const unsigned char *flag_j2;
     double *fpart;
-    int nslab, P, G, rank, TB, NG, NGo, Dmax, Q;
-    int WG, Q2;             // row groups per pair-kernel workgroup (slab_j layout); Q2 = (Dmax + 1) * RT of the far pass
+    int nslab, P, G, rank, TB;
+    int CS, CS2;            // blocks per column tile of slab_j / slab_j2 (N3Args::slab_j)
     int RT;                 // tiles per Newton-3 row group of this engine (1, 2 or 4)
 };
 

@@ -894,7 +894,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         if (B >= a.NG) B -= a.NG;
         const bool owned = valid && ((d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B));
         c = RT * B + l;                                 // column tile (global)
-        blk = (size_t)bx * a.Q + (size_t)e * RT + l;
+        blk = (size_t)c * a.CS + (size_t)(a.by_group ? (int)bx : e / W);   // N3Args::slab_j
         unsigned mb = 0;
         desc = 0;
         if (owned) {
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(kTile, 5) void pair_n3_f32_kernel(N3Args a)
         const bool own_pair = (d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B);
         for (int l = 0; l < kRowTiles; ++l) {
             const int c = kRowTiles * B + l;
-            const size_t blk = (size_t)Al * a.Q + (size_t)d * kRowTiles + l;
+            const size_t blk = (size_t)c * a.CS + (size_t)(a.by_group ? Al : d);   // N3Args::slab_j
             unsigned desc = 0;
             if (own_pair && d != 0)                        // the diagonal group is always a NEAR (fp64) pair
                 desc = (unsigned)__builtin_amdgcn_readfirstlane((int)a.desc[(size_t)Al * a.T + c]);   // built from mask_far
@@ -1582,6 +1582,7 @@ __global__ __launch_bounds__(kBlock) void drift_kick_kernel(IntegrateArgs a)
     }
 }
 
+
 // ---------------------------------------------------------------------------
 // K3a: deterministic reduction of the partial-acceleration slabs (fixed order: row-side
 // slices, then column-side blocks by ascending owned row group).  See ReduceArgs.
@@ -1607,38 +1608,46 @@ __global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
         }
     }
     if constexpr (N3) {
+        // The column tile's blocks lie together (N3Args::slab_j): block j of [0, CS) is added when its flag is set, wave q
+        // taking j = q, q + 4, ... in ascending order.  The flags of 64 blocks are read at once (one byte per lane, a
+        // ballot, the next 64 requested before the current ones are used), and the blocks the ballot names are loaded four
+        // at a time: a stream of independent loads, nothing is read for a block nobody wrote.
         const int c = g * a.TB + blockIdx.x;                    // global column tile (= this workgroup's tile)
-        const int B = c / a.RT, l = c - B * a.RT;
-        const int A0 = a.rank * a.NGo;
-        // fp64 pass: one block per (pair-kernel workgroup of WG consecutive row groups, column tile)
-        const int nwg = (a.NGo + a.WG - 1) / a.WG;
-        for (int gi = q; gi < nwg; gi += kWavesPerBlock) {
-            int e = B - (A0 + gi * a.WG);
-            if (e < 0) e += a.NG;
-            if (e > a.Dmax + a.WG - 1) continue;
-            const size_t blk = (size_t)gi * a.Q + (size_t)e * a.RT + l;
-            if (a.flag_j[blk]) {
-                const double *b = a.slab_j + blk * (3 * kTile) + lane;
-                s[0] += b[0];
-                s[1] += b[kTile];
-                s[2] += b[2 * kTile];
-            }
-        }
-        // fp32 far pass of the mixed-precision mode: one block per (row group, column tile)
-        if (a.slab_j2) {
-            for (int Al = q; Al < a.NGo; Al += kWavesPerBlock) {
-                int d = B - (A0 + Al);
-                if (d < 0) d += a.NG;
-                if (d > a.Dmax) continue;
-                const size_t blk = (size_t)Al * a.Q2 + (size_t)d * a.RT + l;
-                if (a.flag_j2[blk]) {
-                    const double *b = a.slab_j2 + blk * (3 * kTile) + lane;
-                    s[0] += b[0];
-                    s[1] += b[kTile];
-                    s[2] += b[2 * kTile];
+        const int qs = __builtin_amdgcn_readfirstlane(q);
+        auto add_blocks = [&](const double *slab, const unsigned char *flags, int CS) {
+            constexpr int U = 4;
+            const size_t base = (size_t)c * CS;
+            unsigned f = lane < CS ? flags[base + lane] : 0u;
+            for (int j0 = 0; j0 < CS; j0 += kTile) {
+                unsigned long long m = __ballot(f != 0u) & (0x1111111111111111ull << qs);
+                const int jn = j0 + kTile + lane;               // (requested after f is in: the counter of loads is in order)
+                const unsigned fn = jn < CS ? flags[base + jn] : 0u;
+                while (m) {
+                    double v[U][3];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        v[u][0] = v[u][1] = v[u][2] = 0.0;      // s + 0.0 == s: fewer than U blocks left
+                        if (m) {
+                            const int j = j0 + __builtin_ctzll(m);
+                            m &= m - 1;
+                            const double *b = slab + (base + j) * (3 * kTile) + lane;
+                            v[u][0] = b[0];
+                            v[u][1] = b[kTile];
+                            v[u][2] = b[2 * kTile];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        s[0] += v[u][0];
+                        s[1] += v[u][1];
+                        s[2] += v[u][2];
+                    }
                 }
+                f = fn;
             }
-        }
+        };
+        add_blocks(a.slab_j, a.flag_j, a.CS);
+        if (a.slab_j2) add_blocks(a.slab_j2, a.flag_j2, a.CS2);   // fp32 far pass of the mixed-precision mode
     }
     part[q][0][lane] = s[0];
     part[q][1][lane] = s[1];
@@ -1873,15 +1882,11 @@ __global__ __launch_bounds__(kBlock) void tile_tail_kernel(ReduceArgs ra, Integr
         s[2] += sl[2 * (size_t)ra.P];
     }
     if constexpr (N3) {
-        const int B = tile / ra.RT, l = tile - B * ra.RT;
-        const int nwg = (ra.NGo + ra.WG - 1) / ra.WG;
+        // the tile's CS blocks, contiguous (N3Args::slab_j)
 #pragma unroll 4
-        for (int gi = q; gi < nwg; gi += kWavesPerBlock) {
-            int e = B - gi * ra.WG;
-            if (e < 0) e += ra.NG;
-            const bool mine = e <= ra.Dmax + ra.WG - 1;
-            const size_t blk = mine ? (size_t)gi * ra.Q + (size_t)e * ra.RT + l : 0;
-            const bool on = mine && ra.flag_j[blk] != 0;
+        for (int j = q; j < ra.CS; j += kWavesPerBlock) {
+            const size_t blk = (size_t)tile * ra.CS + j;
+            const bool on = ra.flag_j[blk] != 0;
             const double *b = ra.slab_j + blk * (3 * kTile) + lane;
             const double b0 = b[0], b1 = b[kTile], b2 = b[2 * kTile];      // (whatever an unwritten block holds is discarded)
             s[0] += on ? b0 : 0.0;
