@@ -833,6 +833,7 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
 }
 
 // (defined with the geometry pre-pass below)
+template <int RT>
 __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, double rc2, int S, int Al, int c,
                                            unsigned &desc_out, unsigned *desc_far, float *desc2);
 
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
                     ga.P = a.P; ga.G = a.G; ga.rank = a.rank; ga.TB = a.TB; ga.T = a.T; ga.W = a.W; ga.RT = 1;
                     ga.L = a.L; ga.invL = a.invL; ga.rc2_skin = a.rc2_skin; ga.rsplit2 = 0.0; ga.pertile_images = 0;
                     unsigned dsc = 0;
-                    (void)tile_class(ga, a.invL, a.rc2, a.S, Al, c, dsc, nullptr, nullptr);
+                    (void)tile_class<1>(ga, a.invL, a.rc2, a.S, Al, c, dsc, nullptr, nullptr);
                     desc = (unsigned)__builtin_amdgcn_readfirstlane((int)dsc);
                 } else {
                     desc = (unsigned)__builtin_amdgcn_readfirstlane((int)a.desc[(size_t)Al * a.T + c]);
@@ -1336,10 +1337,11 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
 // boxes (= min / max over its 256 particles).
 // ---------------------------------------------------------------------------
 // -> false: the pair kernel does not visit (row group Al, column tile c).  desc_far / desc2: NULL = not wanted.
+// (RT = tiles per row group, a template parameter: the loops over the row tiles unroll and their small arrays stay in registers)
+template <int RT>
 __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, double rc2, int S, int Al, int c,
                                            unsigned &desc_out, unsigned *desc_far, float *desc2)
 {
-    const int RT = a.RT;
     {   // only the (row group, column group) pairs the pair kernel visits: offset d = (B - A) mod NG in 0 .. NG / 2,
         // the pair at exactly NG / 2 from its lower-numbered side (pair_n3_kernel's own_pair)
         const int NG = a.T / RT, A = a.rank * (a.TB / RT) + Al, B = c / RT;
@@ -1374,6 +1376,11 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
             keep = keep && near;
         }
         mb |= (unsigned)keep << k;
+    }
+    if (mb == 0 && mb_far == 0) {                            // nothing inside the cutoff: the pair kernels look no further
+        desc_out = 0;
+        if (desc_far) desc_far[(size_t)Al * a.T + c] = 0;
+        return true;
     }
     double sx = 0.0, sy = 0.0, sz = 0.0;
     const double lo[3] = {glo[0] - cbx[3], glo[1] - cbx[4], glo[2] - cbx[5]};
@@ -1510,6 +1517,7 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
     return true;
 }
 
+template <int RT>
 __global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, double invL, double rc2, int S, unsigned *desc,
                                                             unsigned *desc_far, float *desc2)
 {
@@ -1517,7 +1525,7 @@ __global__ __launch_bounds__(kBlock) void tile_class_kernel(GeometryArgs a, doub
     const int Al = blockIdx.y;                                 // owned row group
     if (c >= a.T) return;
     unsigned d = 0;
-    if (tile_class(a, invL, rc2, S, Al, c, d, desc_far, desc2)) desc[(size_t)Al * a.T + c] = d;
+    if (tile_class<RT>(a, invL, rc2, S, Al, c, d, desc_far, desc2)) desc[(size_t)Al * a.T + c] = d;
 }
 
 // ---------------------------------------------------------------------------
@@ -2106,8 +2114,13 @@ hipError_t launch_tile_mask(const GeometryArgs &a, hipStream_t s)
 hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int S, int NGo, unsigned *desc, unsigned *desc_far,
                              float *desc2, hipStream_t s)
 {
-    hipLaunchKernelGGL(tile_class_kernel, dim3((a.T + kBlock - 1) / kBlock, NGo), dim3(kBlock), 0, s, a, invL, rc2, S, desc,
-                       desc_far, desc2);
+    const dim3 grid((a.T + kBlock - 1) / kBlock, NGo);
+    if (a.RT == 1)
+        hipLaunchKernelGGL(tile_class_kernel<1>, grid, dim3(kBlock), 0, s, a, invL, rc2, S, desc, desc_far, desc2);
+    else if (a.RT == 2)
+        hipLaunchKernelGGL(tile_class_kernel<2>, grid, dim3(kBlock), 0, s, a, invL, rc2, S, desc, desc_far, desc2);
+    else
+        hipLaunchKernelGGL(tile_class_kernel<kRowTiles>, grid, dim3(kBlock), 0, s, a, invL, rc2, S, desc, desc_far, desc2);
     return hipGetLastError();
 }
 
