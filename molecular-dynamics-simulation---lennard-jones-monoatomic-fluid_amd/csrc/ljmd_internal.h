@@ -156,7 +156,7 @@ struct SortArgs {
 
 hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s, size_t dyn_lds = 0);   // dispatches on a.RT, wg_waves
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s);   // dispatches on a.RT, wg_waves
 hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, int phase /* 0 all, 1 positions, 2 velocities */, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);

@@ -594,31 +594,6 @@ __device__ __forceinline__ double rows_sum(double v)
     return __hiloint2double((int)h2[0], (int)l2[0]) + __hiloint2double((int)h2[1], (int)l2[1]);
 }
 
-// pair_apply without control flow: a pair outside the cutoff gets u = 0, and every term it adds is an exact zero
-// (fma(0, d, a) == a for finite d: the cluster passes have no padding slot).  The compiler turns the `if` of
-// pair_apply into exec-mask regions with a dozen register copies at every merge when the loop is unrolled this far;
-// the select costs two 32-bit moves.
-template <bool ENERGY>
-__device__ __forceinline__ void pair_apply_select(double u, double dx, double dy, double dz, double r2, double rc2,
-                                                  double &ax, double &ay, double &az, double &jx, double &jy, double &jz,
-                                                  double &s12, double &s6)
-{
-    u = (r2 < rc2) ? u : 0.0;
-    const double u3 = u * u * u;
-    const double u6 = u3 * u3;
-    if constexpr (ENERGY) {
-        s12 += u6;
-        s6 += u3;
-    }
-    const double g = fma(2.0, u6, -u3) * u;
-    ax = fma(g, dx, ax);
-    ay = fma(g, dy, ay);
-    az = fma(g, dz, az);
-    jx = fma(-g, dx, jx);
-    jy = fma(-g, dy, jy);
-    jz = fma(-g, dz, jz);
-}
-
 // 16 rotation steps of one column cluster (replicated over the four DPP rows) against the wave's RT row tiles;
 // park = &parked[32 * cluster + (lane & 15)]: entry + 16 - s is the particle a rotation by s inside the row brings
 template <int RT, bool MASKED, bool BATCH, bool ENERGY>
@@ -2065,16 +2040,15 @@ hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s, size_t dyn_lds)
+hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s)
 {
     // 3 waves per SIMD (168 VGPRs, no spills) is the measured optimum of the register budget; wg_waves = waves
     // (= consecutive row groups) per workgroup, 2 and 4 only for 4-tile row groups
     // a.energy == 0 (forces only) exists for the one-wave workgroups; the LDS-combining forms always keep the sums
-    // (dyn_lds: unused dynamic LDS that only limits how many waves share a CU -- small systems, see ljmd_create)
     if (a.RT == 1 && !a.energy)
-        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, false>), grid, dim3(kTile), dyn_lds, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, false>), grid, dim3(kTile), 0, s, a);
     else if (a.RT == 1)
-        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, true>), grid, dim3(kTile), dyn_lds, s, a);
+        hipLaunchKernelGGL((pair_n3_kernel<3, 1, 1, true>), grid, dim3(kTile), 0, s, a);
     else if (a.RT == 2 && !a.energy)
         hipLaunchKernelGGL((pair_n3_kernel<3, 2, 1, false>), grid, dim3(kTile), 0, s, a);
     else if (a.RT == 2)
