@@ -32,6 +32,9 @@ PairArgs pair_args(ljmd_t *h, bool fast)
     a.slab = h->d_slab;
     a.wg_part = h->d_wg_part;
     a.mask = h->d_mask;
+    a.bbox = h->d_bbox;
+    a.inline_mask = (fast && h->fuse_tail && !h->use_n3) ? 1 : 0;
+    a.rc2_skin = h->rc2 * (1.0 + 1e-10);
     a.n = h->n;
     a.S = h->S;
     a.P = h->P;
@@ -276,8 +279,8 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (!h->use_n3) ga.mask_far = nullptr;
         if (!h->boxes_valid) LJMD_HIP(h, launch_tile_boxes(ga, h->stream));
         h->boxes_valid = false;                    // good for this evaluation only
-        if (h->use_n3 && h->fuse_tail)
-            ;               // small single-rank system: the pair kernel's waves work their pass descriptors out themselves
+        if (h->fuse_tail)
+            ;               // small single-rank system: the pair kernel's waves work their pass descriptors / mask words out themselves
         else if (h->use_n3)      // tile-pair test + pass descriptors of the Newton-3 kernels in one launch (mixed mode: NEAR and FAR)
             LJMD_HIP(h, launch_tile_class(ga, h->invL, h->rc2, h->S, h->NGo, h->d_desc,
                                           h->mode == LJMD_PRECISION_FP32_FORCE ? h->d_desc_far : nullptr, h->d_desc2, h->stream));

@@ -33,6 +33,10 @@ struct PairArgs {
     double *slab;           // [nslab][3][P] raw partial accelerations of the owned rows
     double *wg_part;        // [n workgroups][2] = s12, s6
     const uint64_t *mask;   // [TB][W] bit (J) of row I set = tile pair must be evaluated
+    const double *bbox;     // tile kernel with inline_mask: the tile boxes [T][kBoxStride]
+    int inline_mask;        // tile kernel, small single-rank systems: the waves work their mask words out themselves
+                            // (tile_mask_kernel's test; `mask` unused) and the step saves a launch
+    double rc2_skin;        // rc^2 (1 + 1e-10) of that test
     int n;                  // total particles
     int S;                  // real particles per rank
     int P;                  // padded axis stride

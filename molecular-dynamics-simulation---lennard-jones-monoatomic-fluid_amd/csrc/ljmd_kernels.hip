@@ -179,6 +179,34 @@ __device__ __forceinline__ void pair_fast(double xi, double yi, double zi,
     }
 }
 
+// Lower bound of |d - m L| over d in [lo, hi], m integer, |d| < 2.5 L.
+__device__ __forceinline__ double axis_gap(double lo, double hi, double L)
+{
+    double g = __builtin_inf();
+#pragma unroll
+    for (int m = -2; m <= 2; ++m) {
+        const double c = m * L;
+        if (lo <= c && c <= hi) return 0.0;
+        g = fmin(g, fmin(fabs(lo - c), fabs(hi - c)));
+    }
+    return g;
+}
+
+// The tile-pair test of the geometry pre-pass (tile_mask_kernel, tile_class): squared lower bound of the minimum-image
+// distance between the boxes of tiles I and J.  A pair of tiles is skipped only when this exceeds rc^2 (1 + 1e-10).
+__device__ __forceinline__ double tile_gap2(const double *bbox, int I, int J, double L)
+{
+    const double *bi = bbox + (size_t)I * kBoxStride;
+    const double *bj = bbox + (size_t)J * kBoxStride;
+    double d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double g = axis_gap(bi[k] - bj[3 + k], bi[3 + k] - bj[k], L);
+        d2 += g * g;
+    }
+    return d2;
+}
+
 // ---------------------------------------------------------------------------
 // K2 (gather, tiled): one wave per 64-particle row tile I (lane = particle), 4 waves per
 // workgroup.  The wave walks its row of the tile-pair mask (bit J set = tile J holds at
@@ -204,7 +232,14 @@ __global__ __launch_bounds__(kBlock) void pair_tiles_kernel(PairArgs a)
     // this workgroup's slice of the column tiles: [J0, J1)  (a.chunk tiles; small systems get many slices)
     const int J0 = blockIdx.y * a.chunk, J1 = min(J0 + a.chunk, a.T);
     for (int w = J0 >> 6; w <= (J1 - 1) >> 6 && J0 < J1; ++w) {
-        uint64_t m = mrow[w];
+        uint64_t m;
+        if (a.inline_mask) {                                 // lane = column tile of this word: tile_mask_kernel's test
+            const int Jl = w * 64 + lane;
+            const bool keep = Jl < a.T && (!(tile_gap2(a.bbox, I, Jl, a.L) > a.rc2_skin) || Jl == I);
+            m = __ballot(keep);
+        } else {
+            m = mrow[w];
+        }
         const int lo = max(J0 - w * 64, 0), hi = min(J1 - w * 64, 64);      // bits of this word inside the slice
         m &= (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
         while (m) {
@@ -1243,19 +1278,6 @@ __global__ __launch_bounds__(kBlock) void tile_boxes_kernel(GeometryArgs a)
     }
 }
 
-// Lower bound of |d - m L| over d in [lo, hi], m integer, |d| < 2.5 L.
-__device__ __forceinline__ double axis_gap(double lo, double hi, double L)
-{
-    double g = __builtin_inf();
-#pragma unroll
-    for (int m = -2; m <= 2; ++m) {
-        const double c = m * L;
-        if (lo <= c && c <= hi) return 0.0;
-        g = fmin(g, fmin(fabs(lo - c), fabs(hi - c)));
-    }
-    return g;
-}
-
 // ---------------------------------------------------------------------------
 // Geometry pre-pass 2: tile-pair mask.  Bit J of row I is cleared only when the boxes
 // prove that every pair (i in I, j in J) has r^2 > rc^2 (1 + 1e-10) under the minimum
@@ -1272,14 +1294,7 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
     const int J = w * 64 + lane;
     bool keep = false, far = false;
     if (J < a.T) {
-        const double *bi = a.bbox + (size_t)I * kBoxStride;
-        const double *bj = a.bbox + (size_t)J * kBoxStride;
-        double d2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double g = axis_gap(bi[k] - bj[3 + k], bi[3 + k] - bj[k], a.L);
-            d2 += g * g;
-        }
+        const double d2 = tile_gap2(a.bbox, I, J, a.L);
         keep = !(d2 > a.rc2_skin) || (J == I);
         if (a.mask_far) {
             // mixed precision: fp64 for boxes closer than r_split and inside the own row group, fp32 beyond
