@@ -956,13 +956,15 @@ def test_stateless_verlet_step_resident_fast_path(monkeypatch):
     assert fast[2] < strict[2]
 
 
+@pytest.mark.parametrize("n", [20000, 16384])
 @pytest.mark.parametrize("wg", ["2", "4"])
-def test_lds_combining_workgroups_equal_one_wave_per_workgroup(wg, monkeypatch, oracle):
+def test_lds_combining_workgroups_equal_one_wave_per_workgroup(wg, n, monkeypatch, oracle):
     """pair_n3_kernel<., 4, W>: W consecutive row groups per workgroup, column-side partial accelerations combined
     in LDS (one slab block per workgroup and column tile).  Same pairs, different summation tree on the column side:
     against the one-wave form to rounding, against the oracle within the usual bounds, and a 25-step trajectory
-    (crosses a re-sort); run-to-run bitwise.  n = 20000 leaves a partially filled last tile and row group."""
-    n = 20000
+    (crosses a re-sort); run-to-run bitwise.  n = 20000 leaves a partially filled last tile and row group, and its 79 row
+    groups are no multiple of W: the column-side blocks are numbered by workgroup (N3Args::slab_j); n = 16384 (64 row
+    groups) numbers them by offset / W."""
     monkeypatch.setenv("LJMD_N3_ROW_TILES", "4")
     p, r, v = synthetic.make_config(n, seed=17)
     po = oracle.derive_params(p.n, p.box_length, p.dt, p.rc)
