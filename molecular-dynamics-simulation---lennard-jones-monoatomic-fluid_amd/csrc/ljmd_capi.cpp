@@ -25,12 +25,16 @@ int fail(const ljmd_t *h, int code, const char *fmt, ...)
 
 bool fast_path_ok(const ljmd_t *h) { return h->rc_allows_fast && h->positions_compact && !h->force_generic; }
 
+// the buffer of workgroup partials of the current force evaluation (two of them alternate when the record of a step is
+// folded by the next step's tail launch)
+double *wg_part_now(ljmd_t *h) { return h->d_wg_part + (h->fuse_tail ? (size_t)h->fold_parity * h->wg_part_stride : 0); }
+
 PairArgs pair_args(ljmd_t *h, bool fast)
 {
     PairArgs a;
     a.pos = h->d_pos;
     a.slab = h->d_slab;
-    a.wg_part = h->d_wg_part;
+    a.wg_part = wg_part_now(h);
     a.mask = h->d_mask;
     a.bbox = h->d_bbox;
     a.inline_mask = (fast && h->fuse_tail && !h->use_n3) ? 1 : 0;
@@ -84,7 +88,7 @@ N3Args n3_args(ljmd_t *h)
     a.slab_i = h->d_slab;
     a.slab_j = h->d_slab_j;
     a.flag_j = h->d_flag_j;
-    a.wg_part = h->d_wg_part;
+    a.wg_part = wg_part_now(h);
     a.S = h->S;
     a.P = h->P;
     a.G = h->G;
@@ -156,7 +160,7 @@ FinalizeArgs finalize_args(ljmd_t *h, int n_wg, bool with_ke, double pair_scale)
 {
     FinalizeArgs a;
     a.pair_scale = pair_scale;
-    a.wg_part = h->d_wg_part;
+    a.wg_part = wg_part_now(h);
     a.ke_part = h->d_ke_part;
     a.ke_tile = nullptr;
     a.ring = h->d_ring;
@@ -358,8 +362,16 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
             ia.pos_tc = h->use_n3 ? h->d_pos_tc : nullptr;
         }
         FinalizeArgs fa = finalize_args(h, h->pending_n_wg, kick, h->pending_scale);
-        fa.ke_tile = h->d_ke_tile;
-        LJMD_HIP(h, launch_tile_tail(reduce_args(h, h->deferred_nslab, h->deferred_n3), ia, fa, kick, drift, h->stream));
+        fa.ke_tile = h->d_ke_tile + (size_t)h->fold_parity * 3 * h->T;
+        // another step of this batch follows: its tail launch folds this step's record beside its own work
+        const bool defer = kick && h->next_drift_hint && h->defer_record;
+        FinalizeArgs prev{};
+        if (h->fold_pending) prev = h->pending_fold;
+        if (defer) ia.ticket = nullptr;
+        LJMD_HIP(h, launch_tile_tail(reduce_args(h, h->deferred_nslab, h->deferred_n3), ia, fa, prev, kick, drift, h->stream));
+        h->fold_pending = defer;
+        h->pending_fold = fa;
+        h->fold_parity ^= 1;                 // the next force evaluation writes the other pair of buffers
         if (q) LJMD_HIP(h, hipEventRecord(q->e[4], h->stream));
         h->drift_prefused = drift;
         h->ring_issued++;
@@ -401,6 +413,10 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
             const int rc_ = comm_end(h);
             if (rc_ != LJMD_OK) return rc_;
         }
+    }
+    if (h->fold_pending) {               // (a record left to "the next tail launch" that is not coming: append it now)
+        LJMD_HIP(h, launch_finalize(h->pending_fold, nullptr, h->stream));
+        h->fold_pending = false;
     }
     if (h->fuse_small && h->pending_n_wg <= 4096) {
         IntegrateArgs ia = integrate_args(h);
@@ -964,6 +980,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     // two launches per step for small single-rank systems (tile_tail_kernel; ljmd_engine.h: fuse_tail)
     h->fuse_tail = h->fuse_small && env_int("LJMD_FUSE_TAIL", 1) != 0 && n_ranks == 1 && n <= 8192 && h->rc_allows_fast &&
                    precision_mode == LJMD_PRECISION_FP64 && (!h->use_n3 || (h->rt == 1 && h->wg_waves == 1));
+    h->defer_record = env_int("LJMD_FUSE_DEFER_RECORD", 1) != 0;
     const bool mixed = precision_mode == LJMD_PRECISION_FP32_FORCE;
     if (mixed && (!h->use_n3 || n < kMixedMinN)) {
         // the fp32 far kernel works on 4-tile row groups and only pays where most pairs are far pairs
@@ -992,7 +1009,8 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_a, P3));
         LJMD_HIP(h, hipMalloc(&h->d_tmp3, P3));
         LJMD_HIP(h, hipMalloc(&h->d_slab, P3 * nslab_max));
-        LJMD_HIP(h, hipMalloc(&h->d_wg_part, 2 * (size_t)n_wg_max * sizeof(double)));
+        h->wg_part_stride = 2 * (size_t)n_wg_max;
+        LJMD_HIP(h, hipMalloc(&h->d_wg_part, (h->fuse_tail ? 2 : 1) * h->wg_part_stride * sizeof(double)));
         if (h->use_n3) {
             const size_t n_blk = (size_t)h->T * h->CS;
             LJMD_HIP(h, hipMalloc(&h->d_slab_j, n_blk * 3 * kTile * sizeof(double)));
@@ -1020,8 +1038,8 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_ticket, sizeof(unsigned)));
         LJMD_HIP(h, hipMemsetAsync(h->d_ticket, 0, sizeof(unsigned), h->stream));
         if (h->fuse_tail) {
-            LJMD_HIP(h, hipMalloc(&h->d_ke_tile, 3 * (size_t)h->T * sizeof(double)));
-            LJMD_HIP(h, hipMemsetAsync(h->d_ke_tile, 0, 3 * (size_t)h->T * sizeof(double), h->stream));
+            LJMD_HIP(h, hipMalloc(&h->d_ke_tile, 2 * 3 * (size_t)h->T * sizeof(double)));        // two buffers, as wg_part
+            LJMD_HIP(h, hipMemsetAsync(h->d_ke_tile, 0, 2 * 3 * (size_t)h->T * sizeof(double), h->stream));
         }
         LJMD_HIP(h, hipMalloc(&h->d_ring, (size_t)kRingCap * kPartialStride * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_ring_pos, sizeof(unsigned)));
@@ -1096,6 +1114,7 @@ int ljmd_set_state(ljmd_t *h, const double *rx, const double *ry, const double *
         h->ring_consumed = h->ring_issued;
         h->forces_pending = false;
         h->gather_done_for_step = false;
+        h->fold_pending = false;            // (a record a failed batch left to its next tail launch)
         h->poisoned = false;
     }
     const size_t S = h->S, P = h->P;

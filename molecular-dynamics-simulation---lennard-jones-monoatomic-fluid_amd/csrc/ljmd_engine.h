@@ -139,6 +139,12 @@ struct ljmd {
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
     int wg_waves = 1;                 // LJMD_N3_WG_WAVES: row groups (waves) per pair-kernel workgroup (1, 2, 4)
+    // two launches per step, record fold off the critical path (tile_tail_kernel): the step's record is folded by the NEXT
+    // tail launch of the batch; the workgroup partials and per-tile v^2 sums it reads alternate between two buffers
+    bool fold_pending = false, defer_record = true;
+    ljmdk::FinalizeArgs pending_fold{};
+    int fold_parity = 0;
+    size_t wg_part_stride = 0;        // doubles per wg_part buffer
     int CS = 0, CS2 = 0, j_by_group = 0;   // slab_j / slab_j2: blocks per column tile, block numbering (N3Args::slab_j)
     int NG = 0, NGo = 0, Dmax = 0, nslab_n = 1, dchunk = 0;
     int rt = kRowTiles;               // tiles per row group (LJMD_N3_ROW_TILES; auto: 4, or 2 / 1 for small systems)

@@ -173,8 +173,8 @@ hipError_t launch_sum_blocks(const double *blocks, double *out, int G, int len, 
 hipError_t launch_finalize(const FinalizeArgs &a, double *fold_scratch /* [2 * kFoldBlocks] or NULL */, hipStream_t s);
 // small single-rank systems: slab reduction + kick + step record (+ the next step's K1 when drift) in one launch, one
 // block per tile; kick without drift = the last step of a batch, neither = a plain force evaluation
-hipError_t launch_tile_tail(const ReduceArgs &ra, const IntegrateArgs &a, const FinalizeArgs &f, bool kick, bool drift,
-                            hipStream_t s);
+hipError_t launch_tile_tail(const ReduceArgs &ra, const IntegrateArgs &a, const FinalizeArgs &f, const FinalizeArgs &prev, bool kick,
+                            bool drift, hipStream_t s);
 hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_time_origin(const TimeOriginArgs &a, bool vacf, int n_origins, hipStream_t s);
 hipError_t launch_tile_boxes(const GeometryArgs &a, hipStream_t s);

@@ -1845,12 +1845,20 @@ __global__ __launch_bounds__(kBlock) void kick_finalize_kernel(IntegrateArgs a, 
 // the pair loop into the same launch (tickets per tile, one device-scope fence pair per WAVE) was 3.4x slower than five
 // launches: profiles/r03_small_n_single_launch_negative.txt.
 // ---------------------------------------------------------------------------
+// The step record (K4) is off the critical path when another step of the batch follows: with a.ticket == NULL this
+// launch leaves its record to the NEXT launch, whose extra block (index = number of tiles) folds it (`prev`) while the
+// tiles are being reduced -- no device-wide fence, no ticket, no last block.  The last launch of a batch draws tickets as
+// before and its last block folds the pending record, then its own.  Records are appended in step order either way.
 template <bool N3, bool KICK, bool DRIFT>
-__global__ __launch_bounds__(kBlock) void tile_tail_kernel(ReduceArgs ra, IntegrateArgs a, FinalizeArgs f)
+__global__ __launch_bounds__(kBlock) void tile_tail_kernel(ReduceArgs ra, IntegrateArgs a, FinalizeArgs f, FinalizeArgs prev)
 {
     __shared__ double part[kWavesPerBlock][3][kTile];
     __shared__ double red[5 * kWavesPerBlock];
     __shared__ bool last;
+    if ((int)blockIdx.x == a.P / kTile) {                       // the extra block: the previous step's record
+        if (prev.ring) finalize_body(prev, red);
+        return;
+    }
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int tile = blockIdx.x;
     const int i = tile * kTile + lane;                          // slot
@@ -1948,6 +1956,7 @@ __global__ __launch_bounds__(kBlock) void tile_tail_kernel(ReduceArgs ra, Integr
             }
         }
     }
+    if (!a.ticket) return;                                 // this step's record: the next launch's extra block
     if (threadIdx.x == 0) {
         __threadfence();                                   // this block's partial is visible device-wide ...
         last = atomicAdd(a.ticket, 1u) == gridDim.x - 1;   // ... before its ticket is
@@ -1955,6 +1964,10 @@ __global__ __launch_bounds__(kBlock) void tile_tail_kernel(ReduceArgs ra, Integr
     __syncthreads();
     if (!last) return;
     __threadfence();                                       // the other blocks' partials, fresh from L2
+    if (prev.ring) {                                       // a record still pending from the step before: first
+        finalize_body(prev, red);
+        __syncthreads();
+    }
     finalize_body(f, red);
     if (threadIdx.x == 0) *a.ticket = 0u;                  // ready for the next launch (stream-ordered)
 }
@@ -2194,11 +2207,14 @@ hipError_t launch_rdf_histogram(const RdfArgs &a, dim3 grid, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_tile_tail(const ReduceArgs &ra, const IntegrateArgs &a, const FinalizeArgs &f, bool kick, bool drift, hipStream_t s)
+hipError_t launch_tile_tail(const ReduceArgs &ra, const IntegrateArgs &a, const FinalizeArgs &f, const FinalizeArgs &prev, bool kick,
+                            bool drift, hipStream_t s)
 {
-    const dim3 grid(a.P / kTile), block(kBlock);
+    // a.ticket == NULL: the record of this launch is folded by the next one; prev.ring != NULL: a record is pending --
+    // it gets an extra block here, or (with tickets) the last block takes it first
+    const dim3 grid(a.P / kTile + ((!a.ticket && prev.ring) ? 1 : 0)), block(kBlock);
     const bool n3 = ra.slab_j != nullptr;
-#define LJMD_TAIL(N3_, KICK_, DRIFT_) hipLaunchKernelGGL((tile_tail_kernel<N3_, KICK_, DRIFT_>), grid, block, 0, s, ra, a, f)
+#define LJMD_TAIL(N3_, KICK_, DRIFT_) hipLaunchKernelGGL((tile_tail_kernel<N3_, KICK_, DRIFT_>), grid, block, 0, s, ra, a, f, prev)
     if (n3) {
         if (kick && drift) LJMD_TAIL(true, true, true);
         else if (kick) LJMD_TAIL(true, true, false);
