@@ -872,13 +872,16 @@ def test_fused_launches_are_bitwise_equal_to_the_separate_kernels(n, monkeypatch
     """LJMD_FUSE=1 (default): tile boxes written by the drift kernel, finalize folded into the kick kernel through
     a last-block ticket -- and, for single-rank systems of up to 8192 particles (LJMD_FUSE_TAIL), a step in TWO launches:
     the pair kernel working its pass descriptors out itself, and tile_tail_kernel (slab reduction + kick + step record +
-    the next step's drift / wrap / half-kick / boxes, one block per tile).  Same values, same reductions, same order ->
-    the same bits as the separate launches, sampled (forces-only) segments included."""
+    the next step's drift / wrap / half-kick / boxes, one block per tile); below 4096 particles the gather kernel works
+    its mask words out itself; and inside a batch the step record is folded by the NEXT tail launch
+    (LJMD_FUSE_DEFER_RECORD).  Same values, same reductions, same order -> the same bits as the separate launches,
+    sampled (forces-only) segments included."""
     p, r, v = synthetic.make_config(n, seed=9)
     out = []
-    for fuse, step in (("1", "1"), ("1", "0"), ("0", "0")):
+    for fuse, step, defer in (("1", "1", "1"), ("1", "1", "0"), ("1", "0", "1"), ("0", "0", "1")):
         monkeypatch.setenv("LJMD_FUSE", fuse)
         monkeypatch.setenv("LJMD_FUSE_TAIL", step)
+        monkeypatch.setenv("LJMD_FUSE_DEFER_RECORD", defer)
         with Engine(p) as eng:
             eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
             e0 = eng.compute_forces()
