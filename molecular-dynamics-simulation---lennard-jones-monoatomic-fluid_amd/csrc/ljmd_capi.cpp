@@ -312,6 +312,8 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
                 fa.flag_j = h->d_flag_j2;
                 fa.desc = h->d_desc_far;
                 fa.CS = h->CS2;
+                fa.by_group = h->G > 1 ? 1 : 0;          // one wave per workgroup whatever wg_waves is: block index = offset d
+                                                         // (CS2 = Dmax + 1) on one rank, the row group on several (CS2 = NGo)
                 fa.xcd_remap = (h->xcd_remap > 0 && (int)fgrid.x >= h->xcd_min_groups && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
                 LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, h->stream));

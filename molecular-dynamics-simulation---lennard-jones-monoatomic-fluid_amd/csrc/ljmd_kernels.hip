@@ -1095,6 +1095,12 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
                                                 float Lf, float invLf, float rc2f,
                                                 float &jx, float &jy, float &jz, float &s12, float &s6)
 {
+    // The per-pair `if (r2 < rc2f)` stays an exec-mask region and the loop stays rolled: measured against branch-free
+    // forms (u = med3(1/r^2, 0, (rc^2 - r^2) 2^60) or a select: +13 ... +30 %), one wave-uniform branch per pair or per
+    // step (+9 % / +40 %), the column offsets parked in LDS instead of rotating (+-0), 2 / 8 / 64 unrolled steps
+    // (+2 % / +-0 / +15 %), 4 or 6 waves per SIMD (+1 % / +2 %): profiles/r04_f32_far_kernel_forms.txt.  The loop runs at
+    // the sum of its instructions' issue costs (tools/ubench_f32mix.hip): 29 % of its wave-level pair evaluations have all
+    // 64 lanes outside the cutoff and skip 13 of their 22 instructions through the region's s_cbranch_execz.
     for (int s = 0; s < kTile; ++s) {
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k)
