@@ -23,7 +23,7 @@ The line of the first rung that delivers one is printed, with `config.launch_mod
 of every rung tried in `config.ladder`.  Under the driver's own `torch.distributed.run` every rank process is such a
 watchdog for its own rank's child in the first rung; only rank 0's goes on to the single-process rungs.
 Environment: LJMD_BENCH_LADDER (comma list of rungs, default all four), LJMD_BENCH_DEADLINES (seconds per rung, default
-210,110,90,90: inside a 600 s driver limit), LJMD_BENCH_SHARE_DEVICE=1 (rehearsal: every rank on device 0),
+190,100,80,80: with the kill grace of every rung inside a 600 s driver limit), LJMD_BENCH_SHARE_DEVICE=1 (rehearsal: every rank on device 0),
 LJMD_BENCH_EXCHANGE=host (rehearsal: the one-process-per-GPU form with its host-staged gloo exchange, nothing else).
 """
 from __future__ import annotations
@@ -49,7 +49,7 @@ HBM_PEAK_GBPS = 8000.0           # MI355X HBM3E (MI355X_MICROARCH.md)
 PKG = ROOT / "molecular-dynamics-simulation---lennard-jones-monoatomic-fluid_amd"
 
 LADDER = ("ranks-rccl", "multi-rccl", "multi-copy", "multi-host")
-DEADLINES = (210.0, 110.0, 90.0, 90.0)
+DEADLINES = (190.0, 100.0, 80.0, 80.0)   # + per timed-out rung <= 12 s of kill grace, 5 s reader join, 5 s pause: < 540 s in all
 EXCHANGE_LABEL = {
     "ranks-rccl": "RCCL all-gather + reduce-scatter inside libljmd.so, one process per GPU",
     "ranks-host": "HOST-STAGED (requested: LJMD_BENCH_EXCHANGE=host): PCIe + gloo, one process per GPU",
@@ -131,18 +131,59 @@ def _log(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def kill_process_tree(proc, grace_s: float = 8.0) -> None:
-    """Ends `proc` and every process it started -- by exact PID, never by pattern: the descendants are listed from
-    /proc (psutil) BEFORE anything is signalled, because torch.distributed.run puts its workers into sessions of
-    their own; SIGTERM first, SIGKILL for whatever is left after `grace_s`."""
+class DescendantTracker:
+    """Remembers every process `proc` has started while it is still alive.  torch.distributed.run puts its workers into
+    sessions of their own, and once the launcher has been reaped /proc no longer links them to it (they are re-parented
+    to init): a listing taken after `proc.wait()` finds nothing.  psutil.Process objects carry the creation time, so a
+    recycled PID is never signalled."""
+
+    def __init__(self, proc, period_s: float = 0.5):
+        import threading
+        self.proc, self.period_s, self.seen = proc, period_s, {}
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._poll, daemon=True)
+        self._th.start()
+
+    def _scan(self) -> None:
+        import psutil
+        try:
+            for c in psutil.Process(self.proc.pid).children(recursive=True):
+                self.seen.setdefault((c.pid, c.create_time()), c)
+        except psutil.Error:
+            pass
+
+    def _poll(self) -> None:
+        while not self._stop.is_set():
+            self._scan()
+            self._stop.wait(self.period_s)
+
+    def stop(self) -> list:
+        """-> the descendants seen so far (alive or not)"""
+        self._stop.set()
+        self._th.join(timeout=2.0)
+        return list(self.seen.values())
+
+
+def kill_process_tree(proc, grace_s: float = 6.0, known=()) -> None:
+    """Ends `proc`, every process it has started (listed from /proc now) and the `known` descendants a
+    DescendantTracker saw earlier -- by exact PID + creation time, never by pattern; SIGTERM first, SIGKILL for
+    whatever is left after `grace_s`."""
     import signal
     import psutil
-    victims = []
+    victims = {}
     try:
         root = psutil.Process(proc.pid)
-        victims = root.children(recursive=True) + [root]
+        for v in root.children(recursive=True) + [root]:
+            victims[(v.pid, v.create_time())] = v
     except psutil.Error:
         pass
+    for v in known:
+        try:
+            if v.is_running():                      # (False for a recycled PID: the creation time differs)
+                victims.setdefault((v.pid, v.create_time()), v)
+        except psutil.Error:
+            pass
+    victims = list(victims.values())
     for v in victims:
         try:
             v.send_signal(signal.SIGTERM)
@@ -181,16 +222,20 @@ def run_attempt(cmd, env, deadline_s: float, relay: bool = True) -> dict:
 
     th = threading.Thread(target=reader, daemon=True)
     th.start()
+    tracker = DescendantTracker(proc)
     try:
         rc = proc.wait(timeout=deadline_s)
         outcome = "ok" if rc == 0 else f"exit {rc}"
+        known = tracker.stop()
     except subprocess.TimeoutExpired:
         _log(f"deadline of {deadline_s:.0f} s passed: ending the attempt's process tree (pid {proc.pid})")
-        kill_process_tree(proc)
+        known = tracker.stop()
+        kill_process_tree(proc, known=known)
         rc, outcome = -9, "timeout"
-    # a rank that died may leave siblings behind (torch.distributed.run ends them, but make sure)
+    # a rank that died may leave siblings behind (torch.distributed.run ends them, but make sure): the child has been
+    # reaped by now, so only the descendants the tracker saw while it lived can still be found
     if rc != 0 and outcome != "timeout":
-        kill_process_tree(proc, grace_s=3.0)
+        kill_process_tree(proc, grace_s=3.0, known=known)
     th.join(timeout=5.0)
     if rc == 0 and box["line"] is None:
         outcome = "no line"
@@ -313,7 +358,14 @@ def committed_parity_summary():
     hits = sorted((ROOT / "profiles").glob("r[0-9][0-9]_mixed_precision_parity_vs_oracle.json"))
     if not hits:
         return None
-    return dict(json.loads(hits[-1].read_text()), source=f"profiles/{hits[-1].name}")
+    doc = dict(json.loads(hits[-1].read_text()), source=f"profiles/{hits[-1].name}")
+    # measured with these kernel sources and the default r_split?  Otherwise the figures belong to another build:
+    # quoted as found under a key that says so (as load_pmc does for the counter summaries)
+    split_now = float(os.environ.get("LJMD_FP32_SPLIT", "5.0"))
+    if doc.get("kernel_source_sha16") != kernel_source_sha16() or float(doc.get("r_split_sigma", 5.0)) != split_now:
+        return {"stale_committed_parity": doc,
+                "note": "measured with other kernel sources or another r_split than this run's: quoted as found"}
+    return doc
 
 
 def mixed_precision_leg(args, p, r, v, etot_fp64, barrier_extra=None) -> dict:
@@ -335,11 +387,12 @@ def mixed_precision_leg(args, p, r, v, etot_fp64, barrier_extra=None) -> dict:
         if barrier_extra:
             barrier_extra.cuda.synchronize()
         el = time.perf_counter() - t0
-        prof = eng.profile_read()
+        prof = eng.profile_read_rank(0)
         e, k, _d, _dd = eng.collect_steps(args.steps)
     et = e + k
     out = {"metric": f"md_steps_per_sec_n{p.n}_mixed_fp32_far_pairs", "value": args.steps / el, "unit": "steps/s",
            "ms_per_step": 1e3 * el / args.steps, "pair_kernels_ms_avg": prof["pair_ms"],
+           "pair_kernels_ms_min": prof["pair_ms_min"], "pair_kernels_ms_median": prof["pair_ms_median"],
            "dtype": "f32 far pairs (box distance > 5 sigma) / f64 near pairs, accumulation and integrator",
            "etot_max_rel_dev_from_fp64_series": float(np.max(np.abs(et - etot_fp64) / np.abs(etot_fp64))),
            "note": "same K steps from the same start as the fp64 headline; not the headline"}
@@ -477,7 +530,8 @@ def measure(args) -> None:
             sim.run(k)
             done += k
         el_liq, profs_liq, _sc = timed(args.steps)
-        liquid = (el_liq, max(q["pair_ms"] for q in profs_liq), done)
+        slow_l = max(profs_liq, key=lambda q: q["pair_ms"])
+        liquid = (el_liq, slow_l["pair_ms"], done, slow_l.get("pair_ms_min"), slow_l.get("pair_ms_median"))
 
     # the production loop's rate: the reference reads epot / d_epot / dd_epot only every output_interval steps
     # (md_simulation_program.f90:361; 100 in its input file), so the driver runs the steps in between with the
@@ -536,7 +590,13 @@ def measure(args) -> None:
             "pair_interactions_per_sec": pairs * steps_per_s,
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS, "traffic": None,
-                         "kernel": kernel_name, "kernel_ms_avg": force_ms, "geometry_prepass_ms_avg": prof["geometry_ms"], "launches_timed": launches,
+                         "kernel": kernel_name, "kernel_ms_avg": force_ms,
+                         # what tells a 1-2 % kernel change from box-to-box scatter: the shortest and the median launch
+                         # of the K timed ones (same HIP events), and the fraction the shortest one reaches
+                         "kernel_ms_min": prof.get("pair_ms_min"), "kernel_ms_median": prof.get("pair_ms_median"),
+                         "frac_of_shortest_launch": (flops_per_launch / (prof["pair_ms_min"] * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS
+                                                     if prof.get("pair_ms_min", 0.0) > 0 else None),
+                         "geometry_prepass_ms_avg": prof["geometry_ms"], "launches_timed": launches,
                          "flop_per_unordered_pair": FLOP_PER_UNORDERED_PAIR,
                          "hbm_algorithmic_GBps": (48.0 * n / n_ranks) / (force_ms * 1e-3) / 1e9 if force_ms > 0 else 0.0,
                          # the other kernels of a step (HIP-event intervals, averages per step): K1 drift/wrap/kick/
@@ -545,7 +605,7 @@ def measure(args) -> None:
                          "drift_kick_algorithmic_bytes": 168.0 * n / n_ranks},
             **({"steps_per_s_liquid": args.steps / liquid[0],
                 "liquid": {"equilibration_steps": liquid[2], "ms_per_step": 1e3 * liquid[0] / args.steps,
-                           "pair_kernel_ms_avg": liquid[1],
+                           "pair_kernel_ms_avg": liquid[1], "pair_kernel_ms_min": liquid[3], "pair_kernel_ms_median": liquid[4],
                            "note": "same K steps timed again in the equilibrated liquid; not the headline"}}
                if liquid else {}),
             **({"steps_per_s_sampled_segment": args.steps / sampled[0],
@@ -618,6 +678,12 @@ def measure(args) -> None:
                 line["roofline"].update({"valu_issue_frac": k["valu_issue_frac"],
                                          "valu_wave_instructions_per_launch": k["SQ_INSTS_VALU"],
                                          "valu_source": f"profiles/{f.name}"})
+                if k.get("clock_ghz_observed"):
+                    # the shader clock the kernel really ran at in the committed counter pass (kernel cycles / the
+                    # dispatch's own duration there); `peak` assumes 2.4 GHz
+                    clk = k["clock_ghz_observed"]
+                    line["roofline"].update({"clock_ghz_observed": clk,
+                                             "frac_at_observed_clock": achieved / (FP64_VALU_PEAK_TFLOPS * clk / 2.4)})
             elif k.get("valu_issue_frac"):
                 stale.update({"valu_issue_frac": k["valu_issue_frac"], "valu_source": f"profiles/{f.name}"})
         # executed fp64 instruction mix of the pair kernel: the flop the kernel really executes per launch (exec-masked

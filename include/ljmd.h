@@ -227,7 +227,8 @@ void ljmd_stateless_reset(void);
 
 /* ---- multi-GPU split-phase API (one process per GPU) -------- */
 
-/* [i0, i1) = particle rows this engine owns. */
+/* [i0, i1) = particle rows this engine owns -- until an ownership migration (ljmd_migrate) after ljmd_set_state: from then on it
+ * owns the set ljmd_particle_ids names and this call fails with LJMD_ERR_STATE. */
 int ljmd_shard_range(const ljmd_t *h, int32_t *i0, int32_t *i1);
 /*
  * Device address of the exchange buffer holding ALL n positions in shard-blocked
@@ -351,6 +352,10 @@ int ljmd_profile_read_ex(ljmd_t *h, double *ms_avg /* [4] */, double *ms_min /* 
  * must be the engine's own rank.  Resets that rank's counters. */
 int ljmd_profile_read_rank(ljmd_t *h, int32_t rank, double *ms_avg /* [6] */, double *ms_min /* [6] */,
                            int32_t *launches);
+/* The same with the median over the launches of each interval: what tells a 1-2 % kernel change from the +-3 % a box
+ * differs from the next by (bench.py: roofline.kernel_ms_min / kernel_ms_median).  Any array may be NULL. */
+int ljmd_profile_read_stats(ljmd_t *h, int32_t rank, double *ms_avg /* [6] */, double *ms_min /* [6] */,
+                            double *ms_median /* [6] */, int32_t *launches);
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "ljmd_profile_read": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),
     "ljmd_profile_read_ex": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int32_p]),
     "ljmd_profile_read_rank": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, c_int32_p]),
+    "ljmd_profile_read_stats": (C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, c_double_p, c_int32_p]),
 }
 
 _lib = None

@@ -1466,6 +1466,11 @@ int ljmd_shard_range(const ljmd_t *h, int32_t *i0, int32_t *i1)
 {
     if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_shard_range: NULL handle");
     if (h->multi) return fail(h, LJMD_ERR_STATE, "ljmd_shard_range: a multi-device handle runs the exchange phases itself");
+    // after an ownership migration the rank owns a SET of particles, not an index range: stitching rank arrays together
+    // by [i0, i1) would silently permute the state
+    if (h->migrated)
+        return fail(h, LJMD_ERR_STATE, "ljmd_shard_range: this rank has migrated since ljmd_set_state and owns the "
+                                       "particles ljmd_particle_ids names, not an index range");
     if (i0) *i0 = h->rank * h->S;
     if (i1) *i1 = (h->rank + 1) * h->S;
     return LJMD_OK;
@@ -1772,7 +1777,8 @@ int ljmd_profile_read(ljmd_t *h, double *ms_avg, int32_t *launches)
 namespace {
 // intervals 0..3 as documented for ljmd_profile_read; 4 = position exchange, 5 = force exchange (averages over the
 // launches that had one; 0 when none did)
-int profile_read_full(ljmd_t *h, double *ms_avg /* [6] */, double *ms_min /* [6] */, int32_t *launches)
+int profile_read_full(ljmd_t *h, double *ms_avg /* [6] */, double *ms_min /* [6] */, int32_t *launches,
+                      double *ms_median = nullptr /* [6] */)
 {
     LJMD_HIP(h, hipSetDevice(h->device));
     LJMD_HIP(h, hipStreamSynchronize(h->stream));
@@ -1780,6 +1786,7 @@ int profile_read_full(ljmd_t *h, double *ms_avg /* [6] */, double *ms_min /* [6]
     double acc[6] = {0, 0, 0, 0, 0, 0};  // pair kernel, geometry pre-pass, drift/kick, reduce+finalize, exchanges
     double lo[6] = {1e300, 1e300, 1e300, 1e300, 1e300, 1e300};
     size_t cnt_x[2] = {0, 0};
+    std::vector<double> all[6];              // per launch, for the medians
     const int from[6] = {2, 1, 0, 3, 5, 7}, to[6] = {3, 2, 1, 4, 6, 8};
     size_t complete = 0;
     for (size_t k = 0; k < h->ev_used; ++k) {
@@ -1801,6 +1808,7 @@ int profile_read_full(ljmd_t *h, double *ms_avg /* [6] */, double *ms_min /* [6]
             if (have[x] && hipEventElapsedTime(&ms, q.e[from[4 + x]], q.e[to[4 + x]]) == hipSuccess) {
                 acc[4 + x] += ms;
                 lo[4 + x] = std::min(lo[4 + x], (double)ms);
+                all[4 + x].push_back(ms);
                 ++cnt_x[x];
             } else if (have[x]) {
                 (void)hipGetLastError();
@@ -1809,6 +1817,7 @@ int profile_read_full(ljmd_t *h, double *ms_avg /* [6] */, double *ms_min /* [6]
         for (int c = 0; c < 4; ++c) {
             acc[c] += one[c];
             lo[c] = std::min(lo[c], one[c]);
+            all[c].push_back(one[c]);
         }
         ++complete;
     }
@@ -1819,6 +1828,12 @@ int profile_read_full(ljmd_t *h, double *ms_avg /* [6] */, double *ms_min /* [6]
         const bool any = c < 4 ? h->ev_used > 0 : cnt_x[c - 4] > 0;
         if (ms_avg) ms_avg[c] = acc[c] / div;
         if (ms_min) ms_min[c] = any ? lo[c] : 0.0;
+        if (ms_median) {
+            std::vector<double> &v = all[c];
+            std::sort(v.begin(), v.end());
+            const size_t m = v.size();
+            ms_median[c] = m == 0 ? 0.0 : (m % 2 ? v[m / 2] : 0.5 * (v[m / 2 - 1] + v[m / 2]));
+        }
     }
     if (launches) *launches = (int32_t)h->ev_used;
     h->ev_used = 0;
@@ -1850,6 +1865,20 @@ int ljmd_profile_read_rank(ljmd_t *h, int32_t rank, double *ms_avg, double *ms_m
     }
     if (rank != h->rank) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_profile_read_rank: this engine is rank %d", h->rank);
     return profile_read_full(h, ms_avg, ms_min, launches);
+}
+
+int ljmd_profile_read_stats(ljmd_t *h, int32_t rank, double *ms_avg, double *ms_min, double *ms_median, int32_t *launches)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_profile_read_stats: NULL handle");
+    if (h->multi) {
+        ljmd_t *e = ljmdm::rank_engine(h, rank);
+        if (!e) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_profile_read_stats: rank %d out of range", rank);
+        const int rc_ = profile_read_full(e, ms_avg, ms_min, launches, ms_median);
+        if (rc_ != LJMD_OK) return fail(h, rc_, "rank %d (device %d): %s", e->rank, e->device, e->err.c_str());
+        return LJMD_OK;
+    }
+    if (rank != h->rank) return fail(h, LJMD_ERR_INVALID_ARG, "ljmd_profile_read_stats: this engine is rank %d", h->rank);
+    return profile_read_full(h, ms_avg, ms_min, launches, ms_median);
 }
 
 // ---- stateless drop-ins ----------------------------------------------------------

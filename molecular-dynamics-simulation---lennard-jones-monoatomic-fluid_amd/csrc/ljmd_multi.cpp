@@ -391,7 +391,8 @@ int team_steps_rank(ljmd_multi *m, int g, int nsteps, bool sampled)
 void team_worker(ljmd_multi *m, int g)
 {
     StepTeam &t = *m->team;
-    (void)hipSetDevice(m->dev[g]);
+    // a thread that could not select its device would launch on device 0 against another device's buffers
+    const hipError_t dev_err = hipSetDevice(m->dev[g]);
     unsigned seen = 0;
     for (;;) {
         int nsteps;
@@ -404,7 +405,13 @@ void team_worker(ljmd_multi *m, int g)
             nsteps = t.nsteps;
             sampled = t.sampled;
         }
-        const int rc_ = team_steps_rank(m, g, nsteps, sampled);
+        int rc_;
+        if (dev_err != hipSuccess) {
+            rc_ = fail(m->eng[g], LJMD_ERR_HIP, "rank thread %d: hipSetDevice(%d) failed: %s", g, m->dev[g], hipGetErrorString(dev_err));
+            t.broken.store(true, std::memory_order_release);       // releases the ranks that wait for this one
+        } else {
+            rc_ = team_steps_rank(m, g, nsteps, sampled);
+        }
         {
             std::lock_guard<std::mutex> lk(t.mu);
             t.rc[g] = rc_;

@@ -337,12 +337,13 @@ class Engine:
     def profile_read_rank(self, rank: int) -> dict:
         """ljmd_profile_read_rank: the same per rank engine, plus the two exchanges of a multi-GPU step
         ('pos_exchange_ms': position all-gather, 'force_exchange_ms': reduce-scatter / all-to-all)"""
-        ms, lo = (C.c_double * 6)(), (C.c_double * 6)()
+        ms, lo, med = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_double * 6)()
         c = C.c_int32()
-        self._ck(self._lib.ljmd_profile_read_rank(self._h, rank, ms, lo, C.byref(c)))
+        self._ck(self._lib.ljmd_profile_read_stats(self._h, rank, ms, lo, med, C.byref(c)))
         names = ("pair_ms", "geometry_ms", "drift_ms", "reduce_ms", "pos_exchange_ms", "force_exchange_ms")
         out = {k: ms[i] for i, k in enumerate(names)}
         out.update({k + "_min": lo[i] for i, k in enumerate(names)})
+        out.update({k + "_median": med[i] for i, k in enumerate(names)})
         out["launches"] = c.value
         return out
 

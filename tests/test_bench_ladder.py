@@ -65,6 +65,28 @@ def test_hung_first_rung_is_killed_and_the_ladder_still_prints_one_line():
     assert not left, left
 
 
+def test_a_rung_that_dies_does_not_leave_its_detached_workers_behind():
+    """A rung whose launcher exits non-zero while a worker in a session of its own lives on (what torch.distributed.run
+    can leave behind): once the launcher has been reaped /proc no longer links the worker to it, so the watchdog must
+    have seen it while the launcher was alive (DescendantTracker) to end it before the next rung starts."""
+    import psutil
+    dying = [sys.executable, "-c",
+             "import subprocess, sys, time; "
+             "subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(601)'], start_new_session=True); "
+             "time.sleep(2.0); sys.exit(3)"]
+    before = {p.pid for p in psutil.process_iter()}
+    out, _ = _run({"LJMD_BENCH_DEADLINES": "20", "LJMD_BENCH_LADDER": "ranks-rccl,multi-copy",
+                   "LJMD_BENCH_ATTEMPT_CMD_RANKS_RCCL": json.dumps(dying),
+                   "LJMD_BENCH_ATTEMPT_CMD_MULTI_COPY": json.dumps(PRINTER)})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1 and [a["outcome"] for a in lines[0]["config"]["ladder"]] == ["exit 3", "ok"]
+    time.sleep(0.5)
+    left = [p for p in psutil.process_iter(["pid", "cmdline"]) if p.info["pid"] not in before and
+            p.info["cmdline"] and "time.sleep(601)" in " ".join(p.info["cmdline"])]
+    assert not left, left
+
+
 def test_every_rung_fails_exit_code_and_no_line():
     out, _ = _run({"LJMD_BENCH_DEADLINES": "20", "LJMD_BENCH_LADDER": "ranks-rccl,multi-copy",
                    "LJMD_BENCH_ATTEMPT_CMD_RANKS_RCCL": json.dumps(FAILER),

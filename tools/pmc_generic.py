@@ -42,6 +42,8 @@ for d in sorted(out.glob("pass*")):
         for r in csv.DictReader(open(f)):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             names.add(r["Counter_Name"])
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
+                acc[short(r["Kernel_Name"])]["dispatch_ns_in_counter_pass"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     passes.append(sorted(names))
 N_SIMD, N_XCD = 1024, 8
 kernels = {}
@@ -53,6 +55,8 @@ for name, c in acc.items():
     cyc = m.get("GRBM_GUI_ACTIVE", 0.0) / N_XCD
     if cyc > 0:
         m["kernel_cycles"] = cyc
+        if m.get("dispatch_ns_in_counter_pass", 0.0) > 0:
+            m["clock_ghz_observed"] = cyc / m["dispatch_ns_in_counter_pass"]
         if m.get("SQ_INSTS_VALU"):
             m["cycles_per_valu_instruction_per_simd"] = N_SIMD * cyc / m["SQ_INSTS_VALU"]
         if "SQ_THREAD_CYCLES_VALU" in m and m.get("SQ_ACTIVE_INST_VALU"):

@@ -80,6 +80,9 @@ if valu_dir.exists() and list(valu_dir.rglob("*counter_collection.csv")):
     vacc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(find("pmc_valu", "counter_collection.csv"))):
         vacc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
+            # the dispatch's own duration in THIS pass: kernel cycles / it = the shader clock the kernel ran at
+            vacc[short(r["Kernel_Name"])]["dispatch_ns_in_counter_pass"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     vk = {}
     for name, c in vacc.items():
         if not name.startswith("ljmdk::"):
@@ -91,6 +94,8 @@ if valu_dir.exists() and list(valu_dir.rglob("*counter_collection.csv")):
         if cyc > 0 and "SQ_INSTS_VALU" in m:
             m["valu_issue_frac"] = m["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * cyc)
             m["cycles_per_valu_instruction_per_simd"] = N_SIMD * cyc / m["SQ_INSTS_VALU"]
+        if cyc > 0 and m.get("dispatch_ns_in_counter_pass", 0.0) > 0:
+            m["clock_ghz_observed"] = cyc / m["dispatch_ns_in_counter_pass"]
         if cyc > 0 and "SQ_ACTIVE_INST_VALU" in m:
             # SQ_ACTIVE_INST_VALU: quad-cycles with a VALU instruction executing, summed over the SIMDs
             m["valu_busy_frac"] = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cyc)
