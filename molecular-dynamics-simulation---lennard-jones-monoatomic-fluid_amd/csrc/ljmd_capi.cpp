@@ -74,6 +74,7 @@ GeometryArgs geometry_args(ljmd_t *h)
     a.mask_far = h->d_mask_far;       // NULL unless mixed precision
     a.rsplit2 = h->r_split * h->r_split;
     a.pertile_images = env_int("LJMD_N3_PERTILE", 1) != 0 ? 1 : 0;
+    a.both_ties = h->half_ties ? 1 : 0;
     return a;
 }
 
@@ -104,6 +105,7 @@ N3Args n3_args(ljmd_t *h)
     a.dchunk = h->dchunk;
     a.xcd_remap = 0;
     a.inline_class = (h->fuse_tail && h->rt == 1 && h->wg_waves == 1) ? 1 : 0;
+    a.half_ties = h->half_ties ? 1 : 0;
     a.rc2_skin = h->rc2 * (1.0 + 1e-10);
     a.energy = h->want_energy ? 1 : 0;
     a.RT = h->rt;
@@ -978,6 +980,16 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         if (small_single) ns = std::max(1, std::min(ns, 4096 / std::max(1, h->NGo)));
         h->dchunk = (n_off + ns - 1) / ns;
         h->nslab_n = (n_off + h->dchunk - 1) / h->dchunk;
+        // one-tile row groups on one rank: work items of EQUAL cost (N3Args::half_ties).  A row tile has (NG - 1) / 2 full
+        // offsets plus one unit made of its self pass and its half of the tie; dchunk = units per item.
+        h->half_ties = h->use_n3 && rt == 1 && wg == 1 && n_ranks == 1 && env_int("LJMD_N3_HALF_TIES", 1) != 0;
+        if (h->half_ties) {
+            const int units = (h->NG - 1) / 2 + 1;
+            int nsl = std::max(1, std::min((target_waves + h->NGo - 1) / h->NGo, units));
+            if (small_single) nsl = std::max(1, std::min(nsl, 4096 / std::max(1, h->NGo)));
+            h->dchunk = (units + nsl - 1) / nsl;
+            h->nslab_n = (units + h->dchunk - 1) / h->dchunk;
+        }
     }
     // two launches per step for small single-rank systems (tile_tail_kernel; ljmd_engine.h: fuse_tail)
     h->fuse_tail = h->fuse_small && env_int("LJMD_FUSE_TAIL", 1) != 0 && n_ranks == 1 && n <= 8192 && h->rc_allows_fast &&

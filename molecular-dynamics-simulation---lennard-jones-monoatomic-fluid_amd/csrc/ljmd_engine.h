@@ -139,6 +139,7 @@ struct ljmd {
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
     int wg_waves = 1;                 // LJMD_N3_WG_WAVES: row groups (waves) per pair-kernel workgroup (1, 2, 4)
+    bool half_ties = false;           // one-tile row groups on one rank: equal-cost work items (N3Args::half_ties)
     // two launches per step, record fold off the critical path (tile_tail_kernel): the step's record is folded by the NEXT
     // tail launch of the batch; the workgroup partials and per-tile v^2 sums it reads alternate between two buffers
     bool fold_pending = false, defer_record = true;

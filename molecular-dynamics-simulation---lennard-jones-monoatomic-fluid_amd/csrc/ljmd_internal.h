@@ -75,6 +75,10 @@ struct N3Args {
     int energy;             // 0: forces only -- the energy sums are not accumulated and the workgroup partials are NaN
     int xcd_remap;          // C > 0: XCD-aware mapping, chunks of C consecutive row groups per XCD (gridDim.x % (8 C) == 0)
     int inline_class;       // RT = 1, one wave per workgroup: the waves compute their pass descriptors themselves (desc unused)
+    int half_ties;          // RT = 1, one wave per workgroup, one rank: slice 0 of a row tile = the tile against itself + (NG
+                            // even) its half of the tie d = NG / 2, both as 32-step half passes, then the offsets
+                            // 1 .. dchunk - 1; slice by >= 1 = the offsets by * dchunk .. by * dchunk + dchunk - 1:
+                            // every work item is dchunk full passes (ljmd_kernels.hip: n3_half_pass)
     double L, invL, rc2;
     double rc2_skin;        // rc^2 (1 + 1e-10) of the tile-pair test (GeometryArgs::rc2_skin), for inline_class
 };
@@ -134,6 +138,7 @@ struct GeometryArgs {
     double L, invL, rc2_skin;   // rc^2 * (1 + 1e-10): skip only when provably outside
     double rsplit2;         // r_split^2
     int pertile_images;     // tile_class: row tiles may take their own periodic image on a single general axis (LJMD_N3_PERTILE)
+    int both_ties;          // tile_class: the tie d = NG / 2 is visited from both sides (N3Args::half_ties)
 };
 
 struct RdfArgs {

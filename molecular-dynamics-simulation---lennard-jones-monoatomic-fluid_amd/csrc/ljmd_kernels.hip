@@ -322,6 +322,39 @@ __device__ __forceinline__ double dpp_rotate(double v)
     return __hiloint2double(hi, lo);
 }
 
+// STRADDLE form of the minimum image.  The differences xi - xj of a (row group, column tile) pass cover a range narrower
+// than L (tile frames), so when no single image serves all pairs the range contains exactly ONE half-integer multiple of
+// L, (n + 1/2) L or (n - 1/2) L, and every pair takes image n or its neighbour on that side.  The pass folds n L + L/2
+// (or n L - L/2) into the column tile once (n3_tile_pass), so that e = xi - xj'' changes sign exactly where the image
+// does, and
+//     d = e - copysign(L/2, e)
+// is the minimum-image displacement: one fp64 subtraction and a v_bfi_b32 on the sign word instead of the multiply,
+// v_rndne_f64 and fma of d - L rndne(d / L) -- 2 fp64 instructions per axis instead of 4.  On the tie e = 0 both images
+// are L/2 away, beyond any rc the fast path accepts; the roundings of the two folds move the decision point by ~ulp(2L),
+// eight orders of magnitude inside the 1e-9 L/2 margin between rc and L/2.  half = 0 makes it the plain difference.
+__device__ __forceinline__ double straddle(double e, double half)
+{
+    return e - __builtin_copysign(half, e);
+}
+
+// the displacement of one pair in the loop variant NU (see pair_n3); sx, sy, sz = the half-box constants of the
+// straddle forms (L/2 on a straddling axis, 0 on a plain one)
+template <int NU>
+__device__ __forceinline__ void pair_disp(double xi, double yi, double zi, double xj, double yj, double zj, double L,
+                                          double invL, double sx, double sy, double sz, double &dx, double &dy, double &dz)
+{
+    static_assert(NU == 7 || NU == 8 || NU == 32 || NU == 33 || NU == 34 || NU == 40, "pair_disp: loop variant");
+    dx = xi - xj; dy = yi - yj; dz = zi - zj;
+    if constexpr (NU == 7) {
+        dx = fma(-L, __builtin_rint(dx * invL), dx);
+        dy = fma(-L, __builtin_rint(dy * invL), dy);
+        dz = fma(-L, __builtin_rint(dz * invL), dz);
+    }
+    if constexpr (NU == 32 || NU == 40) dx = straddle(dx, sx);
+    if constexpr (NU == 33 || NU == 40) dy = straddle(dy, sy);
+    if constexpr (NU == 34 || NU == 40) dz = straddle(dz, sz);
+}
+
 // ENERGY = false: the two energy sums are not accumulated (steps whose observables nobody reads, see N3Args::energy)
 template <bool LANE_PRED, int NU, bool INNER = false, bool ENERGY = true>
 __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
@@ -332,21 +365,14 @@ __device__ __forceinline__ void pair_n3(double xi, double yi, double zi,
                                         double &jx, double &jy, double &jz,
                                         double &s12, double &s6)
 {
-    // NU < 8: bit k set = axis k needs the general minimum image (4 instructions); clear = the image is the
-    // same for the whole (row group, column tile) and the shift is subtracted (2 instructions)
-    // NU == 8: the common image is n = 0 on all three axes: d = xi - xj (1 instruction per axis)
-    // NU == 16 + a: every axis has a common image and only axis a's is non-zero: one subtraction more on that
-    // axis, none on the others ((d - 0.0) == d, so this is the NU == 0 result bit for bit)
-    // NU == 24 + a: axis a general, the two others with the common image n = 0 (same remark)
-    // The common image is added to the column tile once per pass (n3_tile_pass), so only NU = 8, 24, 25, 26, 7 are
-    // instantiated (the shift-subtracting forms NU = 0..6, 16..18 are what the fold replaced).
-    constexpr bool gx = (NU < 8 && (NU & 1)) || NU == 24, gy = (NU < 8 && (NU & 2)) || NU == 25,
-                   gz = (NU < 8 && (NU & 4)) || NU == 26;
-    constexpr bool px = NU == 8 || (NU >= 16 && NU != 16 && NU != 24), py = NU == 8 || (NU >= 16 && NU != 17 && NU != 25),
-                   pz = NU == 8 || (NU >= 16 && NU != 18 && NU != 26);
-    const double dx = px ? (xi - xj) : gx ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
-    const double dy = py ? (yi - yj) : gy ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
-    const double dz = pz ? (zi - zj) : gz ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
+    // NU == 7: all three axes with the general minimum image d - L rndne(d / L) (4 instructions per axis)
+    // NU == 8: the common image of every axis is folded into the column tile (n3_tile_pass): d = xi - xj
+    // NU == 32 + a: axis a STRADDLES one half-box distance (below), the two others as NU == 8
+    // NU == 40: the straddle form on all three axes, the half-box constant of a plain axis being 0
+    // (the per-pair shift-subtracting forms NU = 0..6, 16..18 and the one-general-axis forms 24..26 are what the fold
+    //  and the straddle form replaced)
+    double dx, dy, dz;
+    pair_disp<NU>(xi, yi, zi, xj, yj, zj, L, invL, sx, sy, sz, dx, dy, dz);
     const double r2 = fma(dz, dz, fma(dy, dy, dx * dx));
     bool in = true;
     if constexpr (!INNER) in = r2 < rc2;       // INNER: the boxes prove r^2 < rc^2 for every pair
@@ -375,13 +401,7 @@ __device__ __forceinline__ void pair_geom(double xi, double yi, double zi, doubl
                                           double invL, double sx, double sy, double sz, double &dx, double &dy,
                                           double &dz, double &r2)
 {
-    constexpr bool gx = (NU < 8 && (NU & 1)) || NU == 24, gy = (NU < 8 && (NU & 2)) || NU == 25,
-                   gz = (NU < 8 && (NU & 4)) || NU == 26;
-    constexpr bool px = NU == 8 || (NU >= 16 && NU != 16 && NU != 24), py = NU == 8 || (NU >= 16 && NU != 17 && NU != 25),
-                   pz = NU == 8 || (NU >= 16 && NU != 18 && NU != 26);
-    dx = px ? (xi - xj) : gx ? mic_fast(xi - xj, L, invL) : (xi - xj) - sx;
-    dy = py ? (yi - yj) : gy ? mic_fast(yi - yj, L, invL) : (yi - yj) - sy;
-    dz = pz ? (zi - zj) : gz ? mic_fast(zi - zj, L, invL) : (zi - zj) - sz;
+    pair_disp<NU>(xi, yi, zi, xj, yj, zj, L, invL, sx, sy, sz, dx, dy, dz);
     r2 = fma(dz, dz, fma(dy, dy, dx * dx));
 }
 
@@ -489,6 +509,22 @@ __device__ __forceinline__ bool uniform_image(double lo, double hi, double L, do
 
 #ifdef LJMD_VARIANT_STATS
 __device__ unsigned long long g_variant_stats[80];
+#endif
+#ifdef LJMD_WAVE_TRACE
+// measurement build (tools/wave_trace.py): per wave of the small-system pair kernels 8 words -- s_memrealtime (100 MHz) at
+// the start, after the pass descriptor, after the rotation loop(s) and at the end, HW_ID, XCC_ID, (heavy passes, work item)
+constexpr int kTraceWaves = 1 << 16;
+__device__ unsigned long long g_wave_trace[kTraceWaves * 8];
+__device__ __forceinline__ unsigned long long trace_now() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void trace_store(unsigned wave_index, unsigned long long t0, unsigned long long t1, unsigned long long t2,
+                                            unsigned heavy, unsigned item)
+{
+    if (wave_index >= (unsigned)kTraceWaves) return;
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));      // HW_REG_HW_ID, all 32 bits
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID
+    unsigned long long *o = g_wave_trace + (size_t)wave_index * 8;
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = trace_now(); o[4] = hw; o[5] = xcc; o[6] = heavy; o[7] = item;
+}
 #endif
 
 // W waves per workgroup (W = 1, 2, 4): the W waves hold W CONSECUTIVE row groups and walk the same column tiles in
@@ -798,15 +834,25 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
     }
     // A common image of the whole tile pair is subtracted from the column tile ONCE, here, instead of from every
     // pair's difference: d = xi - (xj + nL).  Three additions per pass replace one subtraction per pair and imaged
-    // axis, and the loop variants with a common image collapse into the ones without (nu 16, 17, 18, 0 -> 8;
-    // 1, 2, 4 -> 24, 25, 26).  xj + nL is rounded at a magnitude <= 2 L where the reference rounds xi - xj at
-    // <= L before its exact minimum-image correction (geometry_pbc.f90:86): the same order of error (<= 2 ulp(L)),
-    // not the same bits.
+    // axis, and the loop variants with a common image collapse into the one without (nu 16, 17, 18, 0 -> 8).
+    // xj + nL is rounded at a magnitude <= 2 L where the reference rounds xi - xj at <= L before its exact
+    // minimum-image correction (geometry_pbc.f90:86): the same order of error (<= 2 ulp(L)), not the same bits.
+    // An axis without a common image STRADDLES (nu 27, 28, 29: that axis alone; 30: two or three of them): the half-box
+    // distance goes into the column tile as well and the loop runs the straddle form (pair_disp).
     const bool general_all = nu == 7;
-    int loop = nu;
+    int loop = 7;
+    double hx = 0.0, hy = 0.0, hz = 0.0;                 // half-box constants of the straddle forms
     if (!general_all) {
-        xj += sx; yj += sy; zj += sz;                   // 0.0 on a general axis and where the image is n = 0
-        loop = (nu == 1) ? 24 : (nu == 2) ? 25 : (nu == 4) ? 26 : (nu >= 24) ? nu : 8;
+        xj += sx; yj += sy; zj += sz;                   // 0.0 where the image is n = 0
+        loop = 8;
+        if (nu >= 27 && nu <= 30) {
+            const double half = 0.5 * a.L;              // exact
+            const unsigned st = (desc >> 22) & 7u, sg = (desc >> 25) & 7u;    // straddling axes; 1 = towards +L/2
+            if (st & 1u) { hx = half; xj += (sg & 1u) ? half : -half; }
+            if (st & 2u) { hy = half; yj += (sg & 2u) ? half : -half; }
+            if (st & 4u) { hz = half; zj += (sg & 4u) ? half : -half; }
+            loop = nu == 30 ? 40 : 32 + (nu - 27);
+        }
     }
     wave_lds_sync<W>();                                // the previous tile's reads are done
 #pragma unroll
@@ -818,10 +864,10 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
     wave_lds_sync<W>();
 #define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
     column_tile_loop<RT, NU_, MASKED_, INNER_, false, ENERGY>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
-                                                  a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
+                                                  a.rc2, hx, hy, hz, jx, jy, jz, s12, s6)
 #define LJMD_LOOP_ALL(NU_, INNER_)                                                                           \
     column_tile_loop<RT, NU_, false, INNER_, (RT == 2 || RT == 4) && LJMD_BATCH_RCP, ENERGY>(                              \
-        xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL, a.rc2, sx, sy, sz, jx, jy, jz, s12, s6)
+        xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL, a.rc2, hx, hy, hz, jx, jy, jz, s12, s6)
     // all row tiles active AND no padding slot anywhere in the tile pair: the unmasked loop with the batched
     // reciprocal; otherwise the masked loop (correct for any mb; a NaN padding slot must not enter a product)
     const bool all4 = mb == ((1u << RT) - 1u) && (full || !LJMD_BATCH_RCP);
@@ -834,12 +880,84 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
 #endif
     if (loop == 8 && inner) { if (all4) LJMD_LOOP_ALL(8, true); else LJMD_LOOP(8, true, true); }
     else if (loop == 8)     { if (all4) LJMD_LOOP_ALL(8, false); else LJMD_LOOP(8, true, false); }
-    else if (loop == 24)    { if (all4) LJMD_LOOP_ALL(24, false); else LJMD_LOOP(24, true, false); }
-    else if (loop == 25)    { if (all4) LJMD_LOOP_ALL(25, false); else LJMD_LOOP(25, true, false); }
-    else if (loop == 26)    { if (all4) LJMD_LOOP_ALL(26, false); else LJMD_LOOP(26, true, false); }
+    else if (loop == 32)    { if (all4) LJMD_LOOP_ALL(32, false); else LJMD_LOOP(32, true, false); }
+    else if (loop == 33)    { if (all4) LJMD_LOOP_ALL(33, false); else LJMD_LOOP(33, true, false); }
+    else if (loop == 34)    { if (all4) LJMD_LOOP_ALL(34, false); else LJMD_LOOP(34, true, false); }
+    else if (loop == 40)    { if (all4) LJMD_LOOP_ALL(40, false); else LJMD_LOOP(40, true, false); }
     else                    { if (all4) LJMD_LOOP_ALL(7, false); else LJMD_LOOP(7, true, false); }
 #undef LJMD_LOOP_ALL
 #undef LJMD_LOOP
+}
+
+// HALF passes of the one-tile-per-group kernel (N3Args::half_ties, small single-rank systems): 32 rotation steps instead
+// of 64, for the two kinds of pass that are not a full 64 x 64 tile pair.
+//   * a tile against itself: steps 1 .. 31 and the lower half of step 32 (each unordered pair once);
+//   * the tie, row tile A against column tile B = A + NG / 2 (NG even): instead of one side owning the whole pass and
+//     the other idling, A < B takes the steps 0 .. 31 against B and B the steps 1 .. 32 against A.  Step s of (A, B)
+//     pairs row i with column i - s; step s' of (B, A) pairs row j with column j - s', i.e. the shift -s' of the first
+//     pass: the two halves cover every shift mod 64 exactly once.
+// Every (row tile, offset slice) work item is then a whole number of full passes -- at n = 4096 exactly 2048 equal items
+// for 1024 SIMDs, where 2112 unequal ones left 64 SIMDs with three (profiles/r04_small_n_wave_trace.txt).
+// The column-side sums stop half way round the wave: lane l ends with the sums of column slot l - t1 and stores them
+// there.  One loop for all image classes: the straddle form on all axes (half-box constant 0 on a plain axis), or the
+// general minimum image (self pass; descriptor class 7).
+template <bool ENERGY>
+__device__ __forceinline__ void n3_half_pass(const N3Args &a, int lane, int c, bool self, bool first_half, unsigned desc,
+                                             double xi, double yi, double zi, double &ax, double &ay, double &az,
+                                             double *parked, double *out /* slab_j block */, double &s12, double &s6)
+{
+    const size_t P = a.P;
+    const double *cb = a.pos + (size_t)c * kTile + lane;           // (single rank)
+    double xj = cb[0], yj = cb[P], zj = cb[2 * P];
+    const int nu = (int)((desc >> 4) & 31u);
+    const bool general = self || nu == 7;
+    double hx = 0.0, hy = 0.0, hz = 0.0;
+    if (!general) {                                                 // the folds of n3_tile_pass
+        xj += (double)((int)((desc >> 11) & 7u) - 2) * a.L;
+        yj += (double)((int)((desc >> 14) & 7u) - 2) * a.L;
+        zj += (double)((int)((desc >> 17) & 7u) - 2) * a.L;
+        if (nu >= 27 && nu <= 30) {
+            const double half = 0.5 * a.L;
+            const unsigned st = (desc >> 22) & 7u, sg = (desc >> 25) & 7u;
+            if (st & 1u) { hx = half; xj += (sg & 1u) ? half : -half; }
+            if (st & 2u) { hy = half; yj += (sg & 2u) ? half : -half; }
+            if (st & 4u) { hz = half; zj += (sg & 4u) ? half : -half; }
+        }
+    }
+    wave_lds_sync<1>();                                             // the previous tile's reads are done
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double val = q == 0 ? xj : q == 1 ? yj : zj;
+        parked[q * kLdsAxis + lane] = val;
+        parked[q * kLdsAxis + kTile + lane] = val;
+    }
+    wave_lds_sync<1>();
+    const int t0 = (self || !first_half) ? 1 : 0, t1 = t0 + kTile / 2;
+    double jx = 0.0, jy = 0.0, jz = 0.0;
+    // entry lane + 64 - t is the particle step t brings; q0[31 - s] with immediate offsets, read one step ahead
+    const double *q0 = parked + lane + kTile - t0 - (kTile / 2 - 1);
+    double nx = q0[kTile / 2 - 1], ny = q0[kLdsAxis + kTile / 2 - 1], nz = q0[2 * kLdsAxis + kTile / 2 - 1];
+#pragma unroll 8
+    for (int s = 0; s < kTile / 2; ++s) {
+        const int t = t0 + s;
+        const double cx = nx, cy = ny, cz = nz;
+        const int nxt = s + 1 < kTile / 2 ? kTile / 2 - 2 - s : 0;  // (the last prefetch is unused)
+        nx = q0[nxt];
+        ny = q0[kLdsAxis + nxt];
+        nz = q0[2 * kLdsAxis + nxt];
+        const bool ok = !self || t < kTile / 2 || lane < kTile / 2;
+        if (general)
+            pair_n3<true, 7, false, ENERGY>(xi, yi, zi, cx, cy, cz, a.L, a.invL, a.rc2, ok, 0.0, 0.0, 0.0, ax, ay, az, jx, jy, jz,
+                                            s12, s6);
+        else
+            pair_n3<true, 40, false, ENERGY>(xi, yi, zi, cx, cy, cz, a.L, a.invL, a.rc2, ok, hx, hy, hz, ax, ay, az, jx, jy, jz,
+                                             s12, s6);
+        jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
+    }
+    const int slot = (lane - t1) & (kTile - 1);                     // whose sums this lane carries after t1 rotations
+    out[slot] = jx;
+    out[kTile + slot] = jy;
+    out[2 * kTile + slot] = jz;
 }
 
 // (defined with the geometry pre-pass below)
@@ -870,6 +988,11 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         by = slot / per;
         bx = ((s / C) * 8u + xcd) * C + s % C;
     }
+#ifdef LJMD_WAVE_TRACE
+    const unsigned long long tr0 = trace_now();
+    unsigned long long tr1 = tr0;
+    unsigned tr_heavy = 0;
+#endif
     const int Al = (int)bx * W + wv;                           // owned row group, wave-uniform
     const bool active = Al < a.NGo;
     const int A = a.rank * a.NGo + Al;                         // its global index
@@ -896,14 +1019,20 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
 
     // tile t = (e - e0) * RT + l of this work item: its column tile c, offset d, slab block, and the mask bits of the
     // wave's RT row tiles (0 = nothing to do: not owned, or every row tile proven outside the cutoff)
+    // half_ties (RT = 1, one wave per workgroup, one rank): slice 0 = the tile against itself, the tie if NG is even (two
+    // half passes: n3_half_pass), then the offsets 1 .. dchunk - 1; slice by >= 1 = the offsets by * dchunk .. + dchunk - 1
+    const bool half_ties = RT == 1 && W == 1 && a.half_ties != 0;
+    const int n_special = half_ties ? 1 + ((a.NG & 1) == 0 && a.NG > 1 ? 1 : 0) : 0;
     auto tile_of = [&](int t, int &c, int &d, int &l, size_t &blk, unsigned &desc) -> unsigned {
-        const int e = e0 + t / RT;
+        int e = e0 + t / RT;
+        if (half_ties) e = by == 0 ? (t == 0 ? 0 : t < n_special ? a.NG / 2 : t - n_special + 1) : e0 + t;
         l = t - (t / RT) * RT;
         d = e - wv;
-        const bool valid = active && d >= 0 && d <= a.Dmax;
+        // (half_ties: the tie is reached through slice 0 only, never as a regular offset)
+        const bool valid = active && d >= 0 && d <= a.Dmax && (!half_ties || (by == 0 && t < n_special) || 2 * d < a.NG);
         int B = A0 + e;
         if (B >= a.NG) B -= a.NG;
-        const bool owned = valid && ((d == 0) || (2 * d < a.NG) || (2 * d == a.NG && A < B));
+        const bool owned = valid && ((d == 0) || (2 * d < a.NG) || (2 * d == a.NG && (A < B || (half_ties && by == 0 && t < n_special))));
         c = RT * B + l;                                 // column tile (global)
         blk = (size_t)c * a.CS + (size_t)(a.by_group ? (int)bx : e / W);   // N3Args::slab_j
         unsigned mb = 0;
@@ -918,6 +1047,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
                     ga.pos = nullptr; ga.bbox = const_cast<double *>(a.bbox); ga.pos_tc = nullptr; ga.mask = nullptr; ga.mask_far = nullptr;
                     ga.P = a.P; ga.G = a.G; ga.rank = a.rank; ga.TB = a.TB; ga.T = a.T; ga.W = a.W; ga.RT = 1;
                     ga.L = a.L; ga.invL = a.invL; ga.rc2_skin = a.rc2_skin; ga.rsplit2 = 0.0; ga.pertile_images = 0;
+                    ga.both_ties = a.half_ties;
                     unsigned dsc = 0;
                     (void)tile_class<1>(ga, a.invL, a.rc2, a.S, Al, c, dsc, nullptr, nullptr);
                     desc = (unsigned)__builtin_amdgcn_readfirstlane((int)dsc);
@@ -932,7 +1062,9 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         }
         return mb;
     };
-    const int nt = (e1 - e0) * RT;
+    const int d_full = (a.NG - 1) / 2;                         // offsets 1 .. d_full are full passes
+    const int nt = half_ties ? (by == 0 ? n_special + min(a.dchunk - 1, d_full) : max(0, min(a.dchunk, d_full + 1 - e0)))
+                             : (e1 - e0) * RT;
 
     {
         double *parked = parked_all[wv];
@@ -943,6 +1075,10 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             unsigned desc;
             const unsigned mb = tile_of(t, c, d, l, blk, desc);
             const bool have = mb != 0;
+#ifdef LJMD_WAVE_TRACE
+            if (t == 0) tr1 = trace_now();
+            tr_heavy += have ? 1u : 0u;
+#endif
             double jx = 0.0, jy = 0.0, jz = 0.0;
             bool stored = false;
             const bool pertile = have && ((desc >> 21) & 1u);
@@ -964,6 +1100,13 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
                     if ((desc >> 20) & 1u) {                       // boundary pass: cluster by cluster (tile_class_kernel)
                         n3_cluster_pass<RT, ENERGY>(a, lane, Al, c, mb, desc, xi, yi, zi, ax, ay, az, parked,
                                                     a.slab_j + blk * (3 * kTile), p12, p6);
+                        stored = true;
+                    }
+                }
+                if constexpr (RT == 1 && W == 1) {
+                    if (half_ties && (d == 0 || 2 * d == a.NG)) {  // the tile against itself, or one half of the tie
+                        n3_half_pass<ENERGY>(a, lane, c, d == 0, A < c, desc, xi[0], yi[0], zi[0], ax[0], ay[0], az[0], parked,
+                                             a.slab_j + blk * (3 * kTile), p12, p6);
                         stored = true;
                     }
                 }
@@ -1020,6 +1163,9 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         }
     }
 
+#ifdef LJMD_WAVE_TRACE
+    const unsigned long long tr2 = trace_now();
+#endif
     if (active) {
         double *si = a.slab_i + (size_t)by * 3 * P;
 #pragma unroll
@@ -1037,6 +1183,9 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         w[0] = t12;
         w[1] = t6;
     }
+#ifdef LJMD_WAVE_TRACE
+    if (lane == 0) trace_store((unsigned)((blockIdx.y * gridDim.x + blockIdx.x) * W + wv), tr0, tr1, tr2, tr_heavy, blockIdx.y * gridDim.x + blockIdx.x);
+#endif
 }
 
 // ===========================================================================
@@ -1173,7 +1322,7 @@ __global__ __launch_bounds__(kTile, 5) void pair_n3_f32_kernel(N3Args a)
             // row offsets below) or general; two or more general axes -> all general (a folded shift on an axis that is
             // then also treated generally is harmless)
             const int nu = (int)((desc >> 4) & 31u);
-            const int gen = (nu == 24 || nu == 1) ? 1 : (nu == 25 || nu == 2) ? 2 : (nu == 26 || nu == 4) ? 4 : nu == 7 ? 7 : 0;
+            const int gen = nu == 27 ? 1 : nu == 28 ? 2 : nu == 29 ? 4 : (nu == 7 || nu == 30) ? 7 : 0;
             const double sx = (double)((int)((desc >> 11) & 7u) - 2) * a.L;
             const double sy = (double)((int)((desc >> 14) & 7u) - 2) * a.L;
             const double sz = (double)((int)((desc >> 17) & 7u) - 2) * a.L;
@@ -1329,6 +1478,8 @@ __global__ __launch_bounds__(kBlock) void tile_mask_kernel(GeometryArgs a)
 //   bit   20     CLUSTER: the pass runs cluster by cluster (n3_cluster_pass) with the direction / thresholds in desc2
 //   bit   21     PERTILE: the row tiles are shifted by whole box lengths on axis (bits 22-23) for this pass, tile k by
 //                (bits 24 + 2k .. 25 + 2k) - 1; the column tile's common image on that axis is the first active tile's
+//   bits 22..27  (PERTILE clear) straddle passes, nu 27..30: bit 22 + q = axis q straddles a half-box distance, bit 25 + q =
+//                that distance is (n + 1/2) L rather than (n - 1/2) L, n = the axis' image field (pair_disp)
 // Same expressions as the former in-kernel classification; the row group's box is the union of its tiles' exact
 // boxes (= min / max over its 256 particles).
 // ---------------------------------------------------------------------------
@@ -1343,7 +1494,7 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
         const int NG = a.T / RT, A = a.rank * (a.TB / RT) + Al, B = c / RT;
         int d = B - A;
         if (d < 0) d += NG;
-        if (!(d == 0 || 2 * d < NG || (2 * d == NG && A < B))) return false;
+        if (!(d == 0 || 2 * d < NG || (2 * d == NG && (A < B || a.both_ties)))) return false;
     }
     double glo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
     double ghi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
@@ -1433,13 +1584,30 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
         }
         inner = far2 < rc2 * (1.0 - 1e-10);
     }
-    if (nu & 1) sx = 0.0;
-    if (nu & 2) sy = 0.0;
-    if (nu & 4) sz = 0.0;
-    if (nu != 0 && nu != 1 && nu != 2 && nu != 4) nu = 7;     // two or more general axes: all general
-    if (nu == 1 && sy == 0.0 && sz == 0.0) nu = 24;          // one general axis, no image on the others
-    else if (nu == 2 && sx == 0.0 && sz == 0.0) nu = 25;
-    else if (nu == 4 && sx == 0.0 && sy == 0.0) nu = 26;
+    // Axes without a common image: the straddle form (pair_disp) whenever the range of differences lies strictly inside
+    // ((h - 1) L, (h + 1) L) around the half-integer h = n +- 1/2 it contains -- always, with tile frames, unless a tile is
+    // wider than half the box -- and every such axis of the pass qualifies; else the general minimum image on all axes.
+    unsigned straddle_axes = 0, straddle_signs = 0;
+    if (nu != 0) {
+        bool ok = true;
+        for (int q = 0; q < 3 && ok; ++q) {
+            if (!((nu >> q) & 1)) continue;
+            const double tlo = lo[q] * invL, thi = hi[q] * invL;
+            const double n = __builtin_rint(0.5 * (tlo + thi));         // = sh[q] / L (uniform_image)
+            const bool up = 0.5 * (tlo + thi) >= n;                       // the half-integer on this side of n
+            const double h = up ? n + 0.5 : n - 0.5;
+            ok = fabs(n) <= 2.0 && tlo > h - 1.0 + 1e-9 && thi < h + 1.0 - 1e-9;
+            straddle_axes |= 1u << q;
+            straddle_signs |= (up ? 1u : 0u) << q;
+        }
+        if (ok) {
+            nu = (straddle_axes == 1u) ? 27 : (straddle_axes == 2u) ? 28 : (straddle_axes == 4u) ? 29 : 30;
+        } else {
+            straddle_axes = straddle_signs = 0;
+            sx = sy = sz = 0.0;                                           // rndne finds every image itself
+            nu = 7;
+        }
+    }
     if (nu == 0) {
         const int nz = (sx != 0.0 ? 1 : 0) | (sy != 0.0 ? 2 : 0) | (sz != 0.0 ? 4 : 0);
         nu = nz == 0 ? 8 : nz == 1 ? 16 : nz == 2 ? 17 : nz == 4 ? 18 : 0;   // none / one axis / several
@@ -1451,6 +1619,8 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
     if (pq >= 0) {                                            // bit 21: per-tile images; 22-23: the axis; 24..31: image + 1 per row tile
         cls |= (1u << 21) | ((unsigned)pq << 22);
         for (int k = 0; k < 4; ++k) cls |= (unsigned)(pm[k] + 1) << (24 + 2 * k);
+    } else {
+        cls |= (straddle_axes << 22) | (straddle_signs << 25);   // (bit 21 clear: these bits name the straddling axes)
     }
     // Cluster pass (pair_n3_kernel: n3_cluster_pass): a pass at the cutoff boundary with a common image on every axis, no
     // padding slot, not inside the diagonal group.  desc2 = the unit direction n from the row group to the (shifted)
@@ -2248,6 +2418,12 @@ hipError_t launch_finalize(const FinalizeArgs &a_in, double *fold_scratch, hipSt
 
 }  // namespace ljmdk
 
+#ifdef LJMD_WAVE_TRACE
+extern "C" int ljmd_debug_wave_trace(unsigned long long *out, int n_waves)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ljmdk::g_wave_trace), (size_t)n_waves * 8 * sizeof(unsigned long long));
+}
+#endif
 #ifdef LJMD_VARIANT_STATS
 extern "C" int ljmd_debug_variant_stats(unsigned long long *out, int reset)
 {
