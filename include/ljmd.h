@@ -328,6 +328,17 @@ int ljmd_read_partials(ljmd_t *h, int32_t nsteps, double *partial);
 int ljmd_combine_scalars(const ljmd_t *h, const double *partials_by_rank, int32_t n_ranks,
                          double *epot, double *ekin, double *d_epot, double *dd_epot);
 
+/*
+ * The reference's switch `use_tail_corrections` (scripts/physics/lj_potential_energy.f90:36, a compile-time
+ * parameter, .true. as shipped; :205-223): on = 0 leaves the three mean-field tail constants out of epot, d_epot and
+ * dd_epot -- of every scalar this handle returns from now on (they are added on the host when the step records are
+ * combined; forces never contain them).  ljmd_stateless_set_tail_corrections does the same for the cached engine behind
+ * the stateless drop-ins ljmd_compute_lj_potential_energy / ljmd_verlet_step (process-wide, default on); the Fortran shim
+ * modules pass their own `use_tail_corrections` parameter through it on every call.
+ */
+int ljmd_set_tail_corrections(ljmd_t *h, int32_t on);
+void ljmd_stateless_set_tail_corrections(int32_t on);
+
 /* ---- measurement --------------------------------------------------------- */
 
 /*

@@ -95,6 +95,8 @@ PROTOTYPES = {
                                      C.POINTER(C.c_void_p), c_int64_p]),
     "ljmd_read_partials": (C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
     "ljmd_combine_scalars": (C.c_int, [C.c_void_p, c_double_p, C.c_int32] + [c_double_p] * 4),
+    "ljmd_set_tail_corrections": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ljmd_stateless_set_tail_corrections": (None, [C.c_int32]),
     "ljmd_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "ljmd_pair_kernel_name": (C.c_char_p, [C.c_void_p]),
     "ljmd_profile_read": (C.c_int, [C.c_void_p, c_double_p, c_int32_p]),

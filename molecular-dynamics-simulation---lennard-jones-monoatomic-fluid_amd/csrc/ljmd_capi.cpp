@@ -566,9 +566,11 @@ void combine_one(const ljmd_t *h, const double *recs, int n_ranks, double *epot,
         kz += r[4];
     }
     // (the kernels already normalised s12, s6 to unordered-pair sums: FinalizeArgs::pair_scale)
-    if (epot) *epot = 4.0 * (s12 - s6) + h->tail_e;                   // :140,:188,:221
-    if (d_epot) *d_epot = 24.0 * (-2.0 * s12 + s6) + h->tail_d;       // :143,:177,:192,:222
-    if (dd_epot) *dd_epot = 24.0 * (26.0 * s12 - 7.0 * s6) + h->tail_dd;  // :178,:193,:223
+    // tail corrections: the reference's compile-time switch use_tail_corrections (lj_potential_energy.f90:36,205-219)
+    const double te = h->tail_on ? h->tail_e : 0.0, td = h->tail_on ? h->tail_d : 0.0, tdd = h->tail_on ? h->tail_dd : 0.0;
+    if (epot) *epot = 4.0 * (s12 - s6) + te;                          // :140,:188,:221
+    if (d_epot) *d_epot = 24.0 * (-2.0 * s12 + s6) + td;              // :143,:177,:192,:222
+    if (dd_epot) *dd_epot = 24.0 * (26.0 * s12 - 7.0 * s6) + tdd;     // :178,:193,:223
     if (ekin) *ekin = 0.5 * (kx + ky + kz);                           // verlet.f90:93-95
 }
 
@@ -1696,6 +1698,15 @@ int ljmd_particle_ids(ljmd_t *h, int32_t *ids)
     return LJMD_OK;
 }
 
+int ljmd_set_tail_corrections(ljmd_t *h, int32_t on)
+{
+    if (!h) return fail(nullptr, LJMD_ERR_INVALID_ARG, "ljmd_set_tail_corrections: NULL handle");
+    // host-side only: the constants are added when the step records are combined (combine_one), on the handle the
+    // caller holds -- for a multi-device handle that is the parent
+    h->tail_on = on != 0;
+    return LJMD_OK;
+}
+
 int32_t ljmd_multi_migrations(const ljmd_t *h)
 {
     return !h ? 0 : h->multi ? ljmdm::migrations(h) : h->migrations;
@@ -1898,6 +1909,7 @@ int ljmd_profile_read_stats(ljmd_t *h, int32_t rank, double *ms_avg, double *ms_
 namespace {
 std::mutex g_cache_mutex;
 ljmd_t *g_cached = nullptr;
+bool g_stateless_tail_on = true;         // ljmd_stateless_set_tail_corrections: applied to the cached engine of the drop-ins
 // what the last ljmd_verlet_step call handed back (r, v, a; 9 n doubles): if the next call passes exactly these
 // bytes again -- the reference's own loop only READS the arrays between steps (md_simulation_program.f90:303-353)
 // -- the resident state IS the caller's state and the upload + spatial re-sort can be skipped
@@ -1922,6 +1934,7 @@ int cached_engine(int32_t n, double L, double dt, double rc, ljmd_t **out)
         g_cached->dt_half = 0.5 * dt;
         g_cached->dt_sq_half = g_cached->dt_half * dt;
     }
+    g_cached->tail_on = g_stateless_tail_on;
     *out = g_cached;
     return LJMD_OK;
 }
@@ -2093,6 +2106,13 @@ int ljmd_time_origin_average(int32_t kind, int32_t n_snap, int32_t n, const doub
     (void)hipFree(d);
     (void)hipFree(dt);
     return rc_;
+}
+
+void ljmd_stateless_set_tail_corrections(int32_t on)
+{
+    std::lock_guard<std::mutex> lk(g_cache_mutex);
+    g_stateless_tail_on = on != 0;
+    if (g_cached) g_cached->tail_on = g_stateless_tail_on;
 }
 
 void ljmd_stateless_reset(void)

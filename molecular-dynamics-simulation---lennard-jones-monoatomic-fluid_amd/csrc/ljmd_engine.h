@@ -68,6 +68,7 @@ struct ljmd {
     int TB = 0, T = 0, W = 0;
     double L = 0, invL = 0, volume = 0, rc = 0, rc2 = 0, dt = 0, dt_half = 0, dt_sq_half = 0;
     double tail_e = 0, tail_d = 0, tail_dd = 0;
+    bool tail_on = true;              // ljmd_set_tail_corrections (the reference's use_tail_corrections, default .true.)
     bool rc_allows_fast = false;      // rc <= (1 - 1e-9) * L/2
     bool positions_compact = false;   // coordinate spread < 2.4 L (always true after a wrap)
     bool have_state = false, have_accel = false;

@@ -15,6 +15,7 @@ module ljmd_c_api
   private
 
   public :: ljmd_compute_lj_potential_energy, ljmd_verlet_step, ljmd_stateless_reset
+  public :: ljmd_set_tail_corrections, ljmd_stateless_set_tail_corrections
   public :: ljmd_create, ljmd_create_multi, ljmd_destroy, ljmd_set_state, ljmd_set_accel, ljmd_set_unwrapped
   public :: ljmd_get_state, ljmd_compute_forces, ljmd_verlet_steps, ljmd_kinetic_energy
   public :: ljmd_last_error, ljmd_device_count, ljmd_profile_enable, ljmd_profile_read
@@ -48,6 +49,19 @@ module ljmd_c_api
 
     subroutine ljmd_stateless_reset() bind(C, name="ljmd_stateless_reset")
     end subroutine
+
+    ! the reference's use_tail_corrections (lj_potential_energy.f90:36): 0 = no tail constants in epot, d_epot, dd_epot
+    subroutine ljmd_stateless_set_tail_corrections(on) bind(C, name="ljmd_stateless_set_tail_corrections")
+      import :: c_int32_t
+      integer(c_int32_t), value :: on
+    end subroutine
+
+    function ljmd_set_tail_corrections(handle, on) bind(C, name="ljmd_set_tail_corrections") result(status)
+      import :: c_int, c_int32_t, c_ptr
+      type(c_ptr), value :: handle
+      integer(c_int32_t), value :: on
+      integer(c_int) :: status
+    end function
 
     function ljmd_create(handle, n, box_length, dt, rc, precision_mode, device, rank, n_ranks) &
         bind(C, name="ljmd_create") result(status)

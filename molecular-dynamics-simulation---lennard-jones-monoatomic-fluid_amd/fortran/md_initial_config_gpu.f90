@@ -14,6 +14,7 @@ program md_initial_config_gpu
   use read_input_files, only: read_simulation_parameters
   use md_init_host
   use ljmd_c_api
+  use lj_potential_energy, only: use_tail_corrections     ! the reference's compile-time switch (lj_potential_energy.f90:36)
   implicit none
 
   type(sim_params) :: params
@@ -41,6 +42,8 @@ program md_initial_config_gpu
   ! ---- energies at t = 0, rescale to the target total energy ------------------------------------
   call ljmd_check(ljmd_create(engine, params%n, params%box_length, params%dt, params%rc, LJMD_PRECISION_FP64, &
                               device, 0_c_int32_t, 1_c_int32_t), c_null_ptr, 'ljmd_create')
+  call ljmd_check(ljmd_set_tail_corrections(engine, merge(1_c_int32_t, 0_c_int32_t, use_tail_corrections)), engine, &
+                  'ljmd_set_tail_corrections')
   call upload()
   call ljmd_check(ljmd_compute_forces(engine, epot, d_epot, dd_epot), engine, 'ljmd_compute_forces')
   call rescale_velocities_to_target_energy(params, state, target_total_energy, epot)

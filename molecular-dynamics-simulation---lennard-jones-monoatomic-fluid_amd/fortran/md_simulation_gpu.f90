@@ -23,6 +23,7 @@ program md_simulation_gpu
   use md_types,         only: sim_params, sim_state, init_state
   use read_input_files, only: read_simulation_parameters
   use ljmd_c_api
+  use lj_potential_energy, only: use_tail_corrections     ! the reference's compile-time switch (lj_potential_energy.f90:36)
   use md_stats,         only: run_statistics, stats_begin, stats_push
   use md_run_outputs,   only: write_run_statistics
   implicit none
@@ -76,6 +77,8 @@ program md_simulation_gpu
                                 LJMD_PRECISION_FP64, int(device, c_int32_t), 0_c_int32_t, 1_c_int32_t), &
                     c_null_ptr, 'ljmd_create')
   end if
+  call ljmd_check(ljmd_set_tail_corrections(engine, merge(1_c_int32_t, 0_c_int32_t, use_tail_corrections)), engine, &
+                  'ljmd_set_tail_corrections')
   ! H2D; the library sets ru <- r (md_simulation_program.f90:229-231)
   call ljmd_check(ljmd_set_state(engine, c_loc(state%rx), c_loc(state%ry), c_loc(state%rz), &
                                  c_loc(state%vx), c_loc(state%vy), c_loc(state%vz)), engine, 'ljmd_set_state')

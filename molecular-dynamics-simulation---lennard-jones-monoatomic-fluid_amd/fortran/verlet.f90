@@ -7,10 +7,11 @@
 ! resident form (ljmd_verlet_steps) is what md_simulation_gpu.f90 uses.
 !==============================================================================
 module verlet
-  use, intrinsic :: iso_c_binding, only: c_loc, c_null_ptr, c_int
+  use, intrinsic :: iso_c_binding, only: c_loc, c_null_ptr, c_int, c_int32_t
   use define_precision, only: dp_kind, int_kind
   use md_types,         only: sim_params, sim_state
-  use ljmd_c_api,       only: ljmd_verlet_step, ljmd_check
+  use ljmd_c_api,       only: ljmd_verlet_step, ljmd_stateless_set_tail_corrections, ljmd_check
+  use lj_potential_energy, only: use_tail_corrections     ! the force routine verlet_step calls (verlet.f90:80) and its switch
   implicit none
   private
   public :: verlet_step
@@ -26,6 +27,7 @@ contains
     if (params%n <= 0_int_kind)    stop 'verlet_step(): params%n must be > 0.'             ! verlet.f90:51
     if (.not. allocated(state%rx)) stop 'verlet_step(): state arrays are not allocated.'  ! verlet.f90:52
 
+    call ljmd_stateless_set_tail_corrections(merge(1_c_int32_t, 0_c_int32_t, use_tail_corrections))
     status = ljmd_verlet_step(params%n, params%box_length, params%dt, params%rc,               &
                  c_loc(state%rx), c_loc(state%ry), c_loc(state%rz),                            &
                  c_loc(state%vx), c_loc(state%vy), c_loc(state%vz),                            &

@@ -317,6 +317,11 @@ class Engine:
         self._ck(self._lib.ljmd_combine_scalars(self._h, _ptr(p), p.shape[0], *[C.byref(o) for o in outs]))
         return tuple(o.value for o in outs)
 
+    def set_tail_corrections(self, on: bool) -> None:
+        """the reference's compile-time switch use_tail_corrections (lj_potential_energy.f90:36): off = epot, d_epot,
+        dd_epot without the three mean-field tail constants"""
+        self._ck(self._lib.ljmd_set_tail_corrections(self._h, 1 if on else 0))
+
     # -- measurement -----------------------------------------------------------
     def profile_enable(self, on: bool = True) -> None:
         self._ck(self._lib.ljmd_profile_enable(self._h, 1 if on else 0))

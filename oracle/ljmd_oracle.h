@@ -33,6 +33,8 @@ int ora_derive_params(ora_params *p, int32_t n, double box_length, double dt, do
 double ora_minimum_image(double dx, double box_length, double inv_box_length);
 void ora_wrap_positions(double *rx, double *ry, double *rz, int32_t n, double box_length);
 void ora_tail_corrections(const ora_params *p, double *t_epot, double *t_d, double *t_dd);
+/* the reference's compile-time switch use_tail_corrections (lj_potential_energy.f90:36), 1 = as shipped */
+void ora_set_tail_corrections(int on);
 void ora_compute_lj_potential_energy(const ora_params *p,
                                      const double *rx, const double *ry, const double *rz,
                                      double *ax, double *ay, double *az,

@@ -50,6 +50,7 @@ def lib() -> C.CDLL:
         L.ora_minimum_image.argtypes = [C.c_double] * 3
         L.ora_wrap_positions.argtypes = [dp, dp, dp, C.c_int32, C.c_double]
         L.ora_tail_corrections.argtypes = [C.POINTER(OraParams), dp, dp, dp]
+        L.ora_set_tail_corrections.argtypes = [C.c_int]
         L.ora_compute_lj_potential_energy.argtypes = [C.POINTER(OraParams)] + [dp] * 9
         L.ora_verlet_step.argtypes = [C.POINTER(OraParams)] + [dp] * 13
         L.ora_ekin_fused.restype = C.c_double
@@ -90,6 +91,11 @@ def tail_corrections(p: OraParams):
     a, b, c = C.c_double(), C.c_double(), C.c_double()
     lib().ora_tail_corrections(C.byref(p), C.byref(a), C.byref(b), C.byref(c))
     return a.value, b.value, c.value
+
+
+def set_tail_corrections(on: bool) -> None:
+    """the reference's compile-time switch use_tail_corrections (lj_potential_energy.f90:36); True = as shipped"""
+    lib().ora_set_tail_corrections(1 if on else 0)
 
 
 def compute_forces(p: OraParams, rx, ry, rz):

@@ -289,3 +289,48 @@ def _isnum(s):
         return True
     except ValueError:
         return False
+
+
+def test_shim_compiled_with_the_tail_switch_off(tmp_path, oracle):
+    """The reference's `use_tail_corrections` is a compile-time parameter of its module lj_potential_energy (:36); the
+    drop-in module declares the same parameter and the library honours it.  Flip it in a copy of OUR shim source, build
+    the thin driver against that copy (amdflang is on the box), run BASELINE config 1: every epot of the energies file
+    is the reference's minus the tail constant, the pressure loses the virial tail, ekin is untouched."""
+    if shutil.which("amdflang") is None:
+        pytest.skip("no amdflang on this box")
+    fsrc = PKG / "fortran"
+    build = tmp_path / "build"
+    (build / "obj").mkdir(parents=True)
+    mods = ["define_precision", "md_types", "read_input_files", "random_numbers", "md_init_host", "ljmd_c_api",
+            "lj_potential_energy", "verlet", "md_stats", "md_run_outputs"]
+    for m in mods:
+        text = (fsrc / f"{m}.f90").read_text()
+        if m == "lj_potential_energy":
+            assert "use_tail_corrections = .true." in text
+            text = text.replace("use_tail_corrections = .true.", "use_tail_corrections = .false.")
+        (build / f"{m}.f90").write_text(text)
+    (build / "md_simulation_gpu.f90").write_text((fsrc / "md_simulation_gpu.f90").read_text())
+    flags = ["-O2", "-ffp-contract=off", "-module-dir", str(build / "obj"), "-I", str(build / "obj")]
+    for m in mods:
+        subprocess.run(["amdflang", *flags, "-c", str(build / f"{m}.f90"), "-o", str(build / "obj" / f"{m}.o")], check=True)
+    exe = build / "md_simulation_notail"
+    subprocess.run(["amdflang", *flags, *[str(build / "obj" / f"{m}.o") for m in mods], str(build / "md_simulation_gpu.f90"),
+                    f"-L{PKG}", "-lljmd", f"-Wl,-rpath,{PKG}", "-o", str(exe)], check=True)
+    run = tmp_path / "run"
+    run.mkdir()
+    src = _workdir(run, "oi100")
+    out = subprocess.run([str(exe)], cwd=run, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    mine = io_formats.read_energies(run / "outputs" / "one_run" / "instantaneous_energies.dat")
+    ref = io_formats.read_energies(src / "instantaneous_energies.dat")
+    from ljmd_amd import read_input_files
+    prm = read_input_files.read_simulation_parameters(run / "inputs" / "input_simulation_parameters.txt").params
+    po = oracle.derive_params(prm.n, prm.box_length, prm.dt, prm.rc)
+    te, td, _tdd = oracle.tail_corrections(po)
+    assert mine.shape == ref.shape
+    # columns: time epot ekin etot T P (7 significant digits in the file)
+    assert np.allclose(mine[:, 2], ref[:, 2], rtol=5e-6, atol=0) and np.allclose(mine[:, 4], ref[:, 4], rtol=5e-6, atol=0)
+    assert np.allclose(ref[:, 1] - mine[:, 1], te, rtol=2e-4, atol=0), (ref[:3, 1] - mine[:3, 1], te)
+    # P = rho T - d_epot / (3 V)  (md_means.f90:227): the virial tail's share
+    dp = -td / (3.0 * po.volume)
+    assert np.allclose(ref[:, 5] - mine[:, 5], dp, rtol=2e-3, atol=0), (ref[:3, 5] - mine[:3, 5], dp)

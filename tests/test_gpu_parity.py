@@ -233,6 +233,64 @@ def test_force_fcc108_known_answer(golden, oracle):
     assert np.max(np.abs(np.stack([st.ax, st.ay, st.az]))) < 1e-12
 
 
+@pytest.mark.parametrize("n", [500, 4096, 20000])
+def test_tail_corrections_switch_off_vs_oracle(oracle, n):
+    """The reference's compile-time switch use_tail_corrections (lj_potential_energy.f90:36, :205-219): with it off the
+    three scalars are the bare pair sums -- ljmd_set_tail_corrections on a handle (gather kernel, one-tile and two-tile
+    Newton-3 kernels), ljmd_stateless_set_tail_corrections for the drop-ins the Fortran shim binds; accelerations and ekin
+    never contain the constants.  Checked against the oracle's else-branch (the C restatement pinned to the reference
+    with the switch on: off, it adds 0.0 instead of the constants, :214-219)."""
+    from ljmd_amd import physics
+    p, r, v = synthetic.make_config(n, seed=5)
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    on = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    oracle.set_tail_corrections(False)
+    try:
+        off = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    finally:
+        oracle.set_tail_corrections(True)
+    te = oracle.tail_corrections(po)
+    assert all(abs(t) > 1e-6 * abs(x) for t, x in zip(te, on[:3]))          # (far above the tolerances below: the test can see them)
+    tol = 1e-13 if n <= 4096 else 1e-12                                       # (the oracle's own running sums: test_production_kernel_...)
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        sc_on = eng.compute_forces()
+        a_on = np.stack(eng.get_state(("a",))["a"])
+        eng.set_tail_corrections(False)
+        sc_off = eng.compute_forces()
+        a_off = np.stack(eng.get_state(("a",))["a"])
+        steps_off = np.stack(eng.verlet_steps(3))
+        eng.set_tail_corrections(True)
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        eng.compute_forces()
+        steps_on = np.stack(eng.verlet_steps(3))
+    for k in range(3):
+        assert rel(sc_on[k], on[k]) <= tol and rel(sc_off[k], off[k]) <= tol, (k, sc_on[k], sc_off[k], on[k], off[k])
+    assert np.array_equal(a_on, a_off)
+    assert np.array_equal(steps_on[1], steps_off[1])                          # ekin: the same trajectory
+    for row, t in zip((0, 2, 3), te):
+        assert np.allclose(steps_on[row] - steps_off[row], t, rtol=1e-9, atol=0.0)
+    # the stateless drop-ins (what fortran/lj_potential_energy.f90 and verlet.f90 call)
+    lib = physics._lib.load()
+    st = init_state(p)
+    st.rx[:], st.ry[:], st.rz[:] = r
+    st.vx[:], st.vy[:], st.vz[:] = v
+    try:
+        lib.ljmd_stateless_set_tail_corrections(0)
+        sc = ljmd_amd.compute_lj_potential_energy(p, st)
+        for k in range(3):
+            assert rel(sc[k], off[k]) <= tol, (k, sc[k], off[k])
+        e1 = ljmd_amd.verlet_step(p, st)
+        lib.ljmd_stateless_set_tail_corrections(1)
+        sc = ljmd_amd.compute_lj_potential_energy(p, st)
+        e2 = ljmd_amd.verlet_step(p, st)
+    finally:
+        lib.ljmd_stateless_set_tail_corrections(1)
+        physics.stateless_reset()
+    assert abs((e1[0] - steps_off[0][0])) <= 1e-9 * abs(e1[0])              # step 1 of the same start, switch off
+    assert abs(sc[0] - e1[0] - te[0]) <= 1e-9 * abs(te[0])                   # the same configuration, switch on
+
+
 def test_force_unwrapped_positions_generic_minimum_image(golden):
     """Positions up to +-3 box lengths outside the box: the library must notice and use the
     exact dnint path (the fast rndne+fma form is only valid for |d/L| < 2.5)."""

@@ -53,6 +53,27 @@ def test_tail_constants(oracle, golden):
     assert abs(te) < 50 and abs(td) < 500
 
 
+def test_tail_switch_off_branch(oracle, golden):
+    """lj_potential_energy.f90:36,214-219: with use_tail_corrections off the reference adds 0.0 instead of the three
+    constants.  The oracle's switch (ora_set_tail_corrections) leaves the pair sums, forces included, bit for bit alone."""
+    g = golden("force_n500")
+    p = oracle.derive_params(500, float(g["L"]), 0.005, float(g["rc"]))
+    r = g["r"]
+    on = oracle.compute_forces(p, r[0].copy(), r[1].copy(), r[2].copy())
+    oracle.set_tail_corrections(False)
+    try:
+        off = oracle.compute_forces(p, r[0].copy(), r[1].copy(), r[2].copy())
+    finally:
+        oracle.set_tail_corrections(True)
+    again = oracle.compute_forces(p, r[0].copy(), r[1].copy(), r[2].copy())
+    te = oracle.tail_corrections(p)
+    for k in range(3):
+        assert on[k] == again[k] and off[k] != on[k]
+        assert abs((on[k] - off[k]) - te[k]) <= 4e-16 * max(abs(on[k]), abs(te[k]))     # one rounding of the final addition
+    for k in (3, 4, 5):
+        assert np.array_equal(on[k], off[k])
+
+
 def _run_traj(oracle, g, nsteps):
     n = int(g["n"])
     p = oracle.derive_params(n, float(g["L"]), float(g["dt"]), float(g["rc"]))
