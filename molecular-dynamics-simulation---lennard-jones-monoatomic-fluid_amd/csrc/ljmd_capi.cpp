@@ -191,33 +191,22 @@ EventSet *next_events(ljmd_t *h)
 // asked) and compose the slot->original permutation.  Performance only (ljmd_sort.hip).
 int resort(ljmd_t *h, bool with_accel)
 {
-    if (h->kd_sort) {
-        // recursive median split (ljmd_sort.hip): one composite-key radix sort per level, along the axis
-        // chosen for that level at set_state (longest remaining extent of the shard)
-        LJMD_HIP(h, launch_iota(h->d_idx, h->P, h->stream));
-        LJMD_HIP(h, hipMemcpyAsync(h->d_idx2, h->d_idx, (size_t)h->P * sizeof(int), hipMemcpyDeviceToDevice,
-                                   h->stream));   // slots S..P-1 (padding) keep their identity in both buffers
-        int *cur = h->d_idx, *nxt = h->d_idx2;
-        for (size_t l = 0; l < h->kd_level_nseg.size(); ++l) {
-            const double *axis = own_block(h) + (size_t)h->kd_axis[l] * h->P;
-            LJMD_HIP(h, kd_level(h->d_cub, h->cub_bytes, axis, h->L, h->d_kd_keys, h->d_kd_keys2, cur, nxt, h->S,
-                                 h->kd_level_nseg[l], h->d_kd_offsets + h->kd_level_off[l], h->stream));
-            std::swap(cur, nxt);
-        }
-        if (cur != h->d_idx2)
-            LJMD_HIP(h, hipMemcpyAsync(h->d_idx2, cur, (size_t)h->P * sizeof(int), hipMemcpyDeviceToDevice,
-                                       h->stream));
-    } else {
-        SortArgs sa;
-        sa.r = own_block(h);
-        sa.keys = h->d_keys;
-        sa.idx = h->d_idx;
-        sa.S = h->S;
-        sa.P = h->P;
-        sa.ncell = h->ncell;
-        sa.L = h->L;
-        LJMD_HIP(h, launch_sort_keys(sa, h->stream));
-        LJMD_HIP(h, sort_pairs(h->d_cub, h->cub_bytes, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2, h->P, h->stream));
+    {
+    // recursive median split (ljmd_sort.hip): one composite-key radix sort per level, along the axis
+    // chosen for that level at set_state (longest remaining extent of the shard)
+    LJMD_HIP(h, launch_iota(h->d_idx, h->P, h->stream));
+    LJMD_HIP(h, hipMemcpyAsync(h->d_idx2, h->d_idx, (size_t)h->P * sizeof(int), hipMemcpyDeviceToDevice,
+                               h->stream));   // slots S..P-1 (padding) keep their identity in both buffers
+    int *cur = h->d_idx, *nxt = h->d_idx2;
+    for (size_t l = 0; l < h->kd_level_nseg.size(); ++l) {
+        const double *axis = own_block(h) + (size_t)h->kd_axis[l] * h->P;
+        LJMD_HIP(h, kd_level(h->d_cub, h->cub_bytes, axis, h->L, h->d_kd_keys, h->d_kd_keys2, cur, nxt, h->S,
+                             h->kd_level_nseg[l], h->d_kd_offsets + h->kd_level_off[l], h->stream));
+        std::swap(cur, nxt);
+    }
+    if (cur != h->d_idx2)
+        LJMD_HIP(h, hipMemcpyAsync(h->d_idx2, cur, (size_t)h->P * sizeof(int), hipMemcpyDeviceToDevice,
+                                   h->stream));
     }
     const size_t bytes3 = 3 * (size_t)h->P * sizeof(double);
     double *sets[4] = {own_block(h), h->d_ru, h->d_v, h->d_a};
@@ -296,10 +285,10 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         if (h->use_n3) {
             const dim3 grid((h->NGo + h->wg_waves - 1) / h->wg_waves, h->nslab_n);     // wg_waves row groups per workgroup
             N3Args na = n3_args(h);
-            // (LJMD_N3_XCD_MIN_GROUPS, default 256 row groups per rank: with 4096 column tiles and 256 row groups -- rank
+            // (kXcdMinGroups = 256 row groups per rank: with 4096 column tiles and 256 row groups -- rank
             //  0 of 4 at n = 262144 -- the mapping still saves 4.7 % (tools/probe_rank.py), with 128 it is neutral, as it
             //  is for single-rank systems of 16384..65536 particles)
-            na.xcd_remap = (h->xcd_remap > 0 && (int)grid.x >= h->xcd_min_groups && grid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
+            na.xcd_remap = (h->xcd_remap > 0 && (int)grid.x >= kXcdMinGroups && grid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
             LJMD_HIP(h, launch_pair_n3(na, grid, h->wg_waves, h->stream));            // all pairs, or the NEAR ones
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y * h->wg_waves;                                      // one partial per wave
@@ -316,7 +305,7 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
                 fa.CS = h->CS2;
                 fa.by_group = h->G > 1 ? 1 : 0;          // one wave per workgroup whatever wg_waves is: block index = offset d
                                                          // (CS2 = Dmax + 1) on one rank, the row group on several (CS2 = NGo)
-                fa.xcd_remap = (h->xcd_remap > 0 && (int)fgrid.x >= h->xcd_min_groups && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
+                fa.xcd_remap = (h->xcd_remap > 0 && (int)fgrid.x >= kXcdMinGroups && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
                 LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, h->stream));
                 nslab *= 2;
@@ -587,7 +576,7 @@ void release(ljmd_t *h)
     for (auto &q : h->ev_pool)
         for (auto &e : q.e) (void)hipEventDestroy(e);
     void *dev[] = {h->d_pos, h->d_ru, h->d_v, h->d_a, h->d_slab, h->d_wg_part, h->d_ke_part, h->d_ring,
-                   h->d_ring_pos, h->d_bbox, h->d_mask, h->d_keys, h->d_keys2, h->d_idx, h->d_idx2,
+                   h->d_ring_pos, h->d_bbox, h->d_mask, h->d_idx, h->d_idx2,
                    h->d_perm, h->d_perm2, h->d_tmp3, h->d_cub, h->d_slab_j, h->d_flag_j, h->d_fpart, h->d_frecv, h->d_fall,
                    h->d_kd_offsets, h->d_kd_keys, h->d_kd_keys2, h->d_mask_far, h->d_slab_j2, h->d_flag_j2, h->d_fold, h->d_ticket,
                    h->d_desc, h->d_desc_far, h->d_desc2, h->d_ke_tile, h->d_pos_tc, h->d_gid0, h->d_mig, h->d_mig_idx, h->d_mig_idx2, h->d_mig_keys,
@@ -871,14 +860,13 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     }
     h->rc_allows_fast = rc <= (1.0 - 1e-9) * 0.5 * box_length;
     // below ~16 tiles there is nothing for the tile mask to skip: keep the caller's order
-    h->sort_enabled = env_int("LJMD_SORT", 1) != 0 && n >= env_int("LJMD_SORT_MIN_N", 1024);
+    h->sort_enabled = env_int("LJMD_SORT", 1) != 0 && n >= 1024;
     h->force_generic = env_int("LJMD_FORCE_GENERIC", 0) != 0;
     h->force_collectives = env_int("LJMD_FORCE_COLLECTIVES", 0) != 0;
     h->fuse_small = env_int("LJMD_FUSE", 1) != 0;
     // measured at n = 262144: chunks of 4 consecutive row groups per XCD -3 % pair-kernel time (19.8 -> 19.1 ms; 2: -1 %,
     // 8 / 16 / 32: +-0, one contiguous eighth per XCD: +10 %), -1.5 % at n = 131072 and 524288 (profiles/r02_xcd_remap_and_prefetch.txt)
     h->xcd_remap = std::max(0, env_int("LJMD_N3_XCD_REMAP", 4));
-    h->xcd_min_groups = std::max(1, env_int("LJMD_N3_XCD_MIN_GROUPS", 256));
     h->inject_failure_at = env_int("LJMD_INJECT_FAILURE_AT_STEP", -1);
     {
         const char *fx = std::getenv("LJMD_FORCE_EXCHANGE");
@@ -893,8 +881,6 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     // the liquid moves ~0.5 sigma against tiles of 4.3 sigma: every 200 steps (20: 25 300 steps/s at n = 4096, 100: 29 500,
     // 200: 30 000, 400: 30 500 -- tools/small_n_rate.py, profiles/r03_small_n_two_launch_step.txt).
     h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", n >= 1000000 ? 5 : n >= 131072 ? 10 : n > 8192 ? 20 : 200));
-    h->ncell = std::max(1, std::min(1023, (int)std::floor(box_length / 1.2)));
-    h->kd_sort = env_int("LJMD_SORT_KD", 1) != 0;
     std::vector<int> kd_offsets;
     {   // k-d levels: segments = runs of whole tiles, halved until every segment is one tile
         const int tiles = (h->S + kTile - 1) / kTile;
@@ -1061,15 +1047,13 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         LJMD_HIP(h, hipMalloc(&h->d_ring_pos, sizeof(unsigned)));
         LJMD_HIP(h, hipMalloc(&h->d_bbox, (size_t)h->T * kBoxStride * sizeof(double)));
         LJMD_HIP(h, hipMalloc(&h->d_mask, (size_t)h->TB * h->W * sizeof(uint64_t)));
-        LJMD_HIP(h, hipMalloc(&h->d_keys, (size_t)h->P * sizeof(unsigned)));
-        LJMD_HIP(h, hipMalloc(&h->d_keys2, (size_t)h->P * sizeof(unsigned)));
         LJMD_HIP(h, hipMalloc(&h->d_idx, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, hipMalloc(&h->d_idx2, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, hipMalloc(&h->d_perm, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, hipMalloc(&h->d_perm2, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, hipMalloc(&h->d_gid0, (size_t)h->P * sizeof(int)));
         LJMD_HIP(h, launch_iota_offset(h->d_gid0, h->S, h->P, h->rank * h->S, h->stream));
-        h->cub_bytes = std::max(sort_temp_bytes(h->P), kd_temp_bytes(h->S));
+        h->cub_bytes = kd_temp_bytes(h->S);
         LJMD_HIP(h, hipMalloc(&h->d_cub, std::max<size_t>(h->cub_bytes, 16)));
         LJMD_HIP(h, hipMalloc(&h->d_kd_keys, (size_t)h->P * sizeof(unsigned long long)));
         LJMD_HIP(h, hipMalloc(&h->d_kd_keys2, (size_t)h->P * sizeof(unsigned long long)));

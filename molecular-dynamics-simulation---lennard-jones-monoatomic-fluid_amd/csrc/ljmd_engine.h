@@ -28,6 +28,7 @@ extern thread_local std::string g_last_error;
 
 constexpr unsigned kRingCap = 4096;     // per-step partial records kept on the device
 constexpr int kTargetWorkgroups = 2048; // >> 256 CUs (8 per CU) for the pair kernels
+constexpr int kXcdMinGroups = 256;      // row groups per rank from which the XCD-aware work mapping is used (neutral below)
 constexpr int kMixedMinN = 16384;       // smallest system the mixed-precision mode accepts
 constexpr long kN3ItemsFor4 = 30000;    // Newton-3 work items (row groups x offsets) a rank needs before 4 ...
 constexpr long kN3ItemsFor2 = 6144;     // ... or 2 tiles per row group pay off
@@ -75,7 +76,7 @@ struct ljmd {
     bool sort_enabled = true;
     bool force_generic = false;       // LJMD_FORCE_GENERIC=1: always take the exact generic kernel (A/B tests)
     bool force_collectives = false;   // LJMD_FORCE_COLLECTIVES=1: a 1-rank engine still issues its RCCL calls (tests)
-    int resort_every = 20, steps_since_sort = 0, ncell = 1;
+    int resort_every = 20, steps_since_sort = 0;
 
     hipStream_t stream = nullptr;
     ncclComm_t comm = nullptr;        // RCCL communicator over the G ranks (multi-GPU only)
@@ -93,7 +94,6 @@ struct ljmd {
     double *d_fold = nullptr;     // [kFoldBlocks][2]
     unsigned *d_ticket = nullptr; // blocks-done counter of the kick kernel with the finalize folded in
     bool want_energy = true;      // false: the next force evaluations skip the energy sums (epot, d_epot, dd_epot = NaN)
-    int xcd_min_groups = 256;     // row groups per rank from which the XCD-aware mapping is used
     int xcd_remap = 0;            // LJMD_N3_XCD_REMAP: consecutive row groups per XCD chunk of the Newton-3 pair kernel (0 = plain mapping)
     bool fuse_small = true;       // LJMD_FUSE: boxes inside the drift kernel, finalize inside the kick kernel
     // LJMD_FUSE_TAIL (default on): small single-rank systems run a step as TWO launches -- the pair kernel with its pass
@@ -119,13 +119,11 @@ struct ljmd {
     unsigned *d_desc_far = nullptr;   // same for the fp32 far kernel of the mixed mode (from mask_far)
     float *d_desc2 = nullptr;     // [NGo][T][8] direction + thresholds of the cluster passes (LJMD_N3_CLUSTERS, default on)
     // sorting scratch
-    unsigned *d_keys = nullptr, *d_keys2 = nullptr;
     int *d_idx = nullptr, *d_idx2 = nullptr, *d_perm = nullptr, *d_perm2 = nullptr;
     double *d_tmp3 = nullptr;     // [3][P]
     void *d_cub = nullptr;
     size_t cub_bytes = 0;
     // k-d ordering (default): per level the segment boundaries in particle units
-    bool kd_sort = true;
     std::vector<int> kd_level_nseg;       // segments at level l
     std::vector<size_t> kd_level_off;     // offset of level l's boundaries inside d_kd_offsets
     std::vector<int> kd_axis;             // split axis of level l: always the longest remaining extent

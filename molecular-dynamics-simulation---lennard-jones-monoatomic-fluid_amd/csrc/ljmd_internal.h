@@ -155,14 +155,6 @@ struct TimeOriginArgs {
     int n_snap, n, max_lag, origin_stride;
 };
 
-struct SortArgs {
-    const double *r;        // own block [3][P]
-    unsigned *keys;         // [P]
-    int *idx;               // [P] iota
-    int S, P, ncell;
-    double L;
-};
-
 hipError_t launch_pair_rows_generic(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_tiles(const PairArgs &a, dim3 grid, hipStream_t s);
 hipError_t launch_pair_n3(const N3Args &a, dim3 grid, int wg_waves, hipStream_t s);   // dispatches on a.RT, wg_waves
@@ -188,10 +180,6 @@ hipError_t launch_tile_class(const GeometryArgs &a, double invL, double rc2, int
                              unsigned *desc_far, float *desc2 /* cluster passes, or NULL: none */, hipStream_t s);
 
 // ljmd_sort.hip
-size_t sort_temp_bytes(int count);
-hipError_t launch_sort_keys(const SortArgs &a, hipStream_t s);
-hipError_t sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out,
-                      const int *idx_in, int *idx_out, int count, hipStream_t s);
 size_t kd_temp_bytes(int count);
 hipError_t launch_iota(int *idx, int P, hipStream_t s);
 hipError_t kd_level(void *temp, size_t temp_bytes, const double *coord_axis, double L, unsigned long long *keys,

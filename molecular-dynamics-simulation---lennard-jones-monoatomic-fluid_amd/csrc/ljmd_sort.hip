@@ -1,51 +1,16 @@
-// ljmd_sort.hip -- spatial re-ordering of the owned shard (performance only).
+// ljmd_sort.hip -- spatial re-ordering of the owned shard (performance only) and the ownership migration of multi-GPU runs.
 //
-// Particles are ordered by the Morton (Z-order) code of their cell on a grid of ~1.2 sigma
-// cells, so that 64 consecutive slots (one tile = one wave) form a compact blob.  Compact
-// tiles are what lets tile_mask_kernel prove that whole 64 x 64 tile pairs lie outside the
-// cutoff.  Correctness never depends on the order: bounding boxes are recomputed exactly
-// from the actual coordinates before every force evaluation.  The (key, slot) radix sort
-// is stable and deterministic, so the summation order -- and hence every bit of the result
-// -- is reproducible run to run.
+// The shard is kept in k-d order (recursive median split, below): 64 consecutive slots (one tile = one wave) are a
+// near-cubic box of exactly 64 particles.  Compact tiles are what lets the tile-pair test prove that whole 64 x 64 tile
+// pairs lie outside the cutoff.  Correctness never depends on the order: bounding boxes are recomputed exactly from the
+// actual coordinates before every force evaluation.  The (key, slot) radix sorts are stable and deterministic, so the
+// summation order -- and hence every bit of the result -- is reproducible run to run.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
 #include "ljmd_internal.h"
 
 namespace ljmdk {
-
-__device__ __forceinline__ unsigned spread10(unsigned v)   // abcdefghij -> a00b00c00...
-{
-    v &= 0x3ffu;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
-}
-
-__global__ __launch_bounds__(kBlock) void sort_keys_kernel(SortArgs a)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= a.P) return;
-    unsigned key = 0xffffffffu;                       // padding stays at the end
-    if (i < a.S) {
-        const double x = a.r[i], y = a.r[a.P + i], z = a.r[2 * (size_t)a.P + i];
-        key = 0xfffffffeu;                            // non-finite coordinates: after all cells
-        if (isfinite(x) && isfinite(y) && isfinite(z)) {
-            const double s = a.ncell / a.L;
-            const double fx = (x - a.L * floor(x / a.L)) * s;
-            const double fy = (y - a.L * floor(y / a.L)) * s;
-            const double fz = (z - a.L * floor(z / a.L)) * s;
-            const unsigned cx = min((unsigned)max((int)fx, 0), (unsigned)(a.ncell - 1));
-            const unsigned cy = min((unsigned)max((int)fy, 0), (unsigned)(a.ncell - 1));
-            const unsigned cz = min((unsigned)max((int)fz, 0), (unsigned)(a.ncell - 1));
-            key = (spread10(cx) << 2) | (spread10(cy) << 1) | spread10(cz);
-        }
-    }
-    a.keys[i] = key;
-    a.idx[i] = i;
-}
 
 __global__ __launch_bounds__(kBlock) void gather3_kernel(const double *src, double *dst, const int *idx, int P)
 {
@@ -247,26 +212,6 @@ hipError_t launch_migrate_select(const double *pos_all, const double *mig_all, c
     hipLaunchKernelGGL(migrate_select_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, pos_all, mig_all, mine,
                        new_pos, ru, v, a, gid0, S, P);
     return hipGetLastError();
-}
-
-size_t sort_temp_bytes(int count)
-{
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                             (const int *)nullptr, (int *)nullptr, count, 0, 32, nullptr);
-    return bytes;
-}
-
-hipError_t launch_sort_keys(const SortArgs &a, hipStream_t s)
-{
-    hipLaunchKernelGGL(sort_keys_kernel, dim3((a.P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t sort_pairs(void *temp, size_t temp_bytes, const unsigned *keys_in, unsigned *keys_out,
-                      const int *idx_in, int *idx_out, int count, hipStream_t s)
-{
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, count, 0, 32, s);
 }
 
 hipError_t launch_gather3(const double *src, double *dst, const int *idx, int P, hipStream_t s)

@@ -1062,6 +1062,41 @@ def test_lds_combining_workgroups_equal_one_wave_per_workgroup(wg, n, monkeypatc
     assert np.abs(wa[1] - ao).max() <= REL_ACCEL * np.abs(ao).max()
 
 
+@pytest.mark.parametrize("wg", ["2", "4"])
+def test_mixed_precision_far_pass_beside_lds_combining_workgroups(wg, monkeypatch, oracle):
+    """The fp32 far pass is always one wave per workgroup and numbers its column-side blocks by offset on one rank
+    (CS2 = Dmax + 1 blocks per column tile), whatever the fp64 near kernel's workgroups do: with W = 2 / 4 and 79 row
+    groups (no multiple of W) the near kernel numbers ITS blocks by workgroup, and the far pass must not inherit that
+    (blocks of neighbouring column tiles would collide and the last tiles write past the slab).  Against the one-wave
+    configuration and the oracle at the mixed mode's bounds; run-to-run bitwise."""
+    from ljmd_amd import _lib
+    n = 20000
+    p, r, v = synthetic.make_config(n, seed=17)
+    po = oracle.derive_params(p.n, p.box_length, p.dt, p.rc)
+    e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
+    ao = np.stack([ax, ay, az])
+    out = {}
+    for w in ("1", wg, wg):
+        monkeypatch.setenv("LJMD_N3_WG_WAVES", w)
+        with Engine(p, precision_mode=_lib.PRECISION_FP32_FORCE) as eng:
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            assert eng.pair_kernel_name() == "pair_n3_f32_kernel"
+            sc0 = np.array(eng.compute_forces())
+            a0 = np.stack(eng.get_state(("a",))["a"])
+            sc = np.stack(eng.verlet_steps(12), axis=1)            # crosses a re-sort
+        out.setdefault(w, []).append((sc0, a0, sc))
+    one, (wa, wb) = out["1"][0], out[wg]
+    assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1]) and np.array_equal(wa[2], wb[2])
+    assert np.isfinite(wa[1]).all()
+    # the far pass is the same code in both: what differs is the near kernel's column-side summation tree
+    assert np.max(np.abs(wa[0] - one[0]) / np.abs(one[0])) < 1e-12
+    assert np.abs(wa[1] - one[1]).max() < 1e-11 * np.abs(one[1]).max()
+    assert np.max(np.abs(wa[2] - one[2]) / np.abs(one[2])) < 1e-9
+    for mine, ref in zip(wa[0], (e_o, d_o, dd_o)):
+        assert rel(mine, ref) <= 5e-9
+    assert np.abs(wa[1] - ao).max() <= 1e-9 * np.abs(ao).max()
+
+
 def test_full_size_invariances_permutation_translation_reflection():
     """Size-independent properties of the force routine at the bench size (n = 262144), where no CPU run of the
     reference exists beyond the single oracle comparison above: the result must not depend on the ORDER of the

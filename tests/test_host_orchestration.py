@@ -53,7 +53,8 @@ def drive(eng, r, v, steps, ranks=1):
 
 # single engines: gather kernel sizes, Newton-3 with 1 / 2 / 4 tiles per row group, padded shards, mixed precision
 for n, env in ((108, {}), (500, {}), (3000, {"LJMD_N3_MIN_N": "1"}), (4096, {}), (16384, {}),
-               (20000, {"LJMD_N3_ROW_TILES": "4", "LJMD_N3_WG_WAVES": "4"}), (16384, {"mode": "1"})):
+               (20000, {"LJMD_N3_ROW_TILES": "4", "LJMD_N3_WG_WAVES": "4"}), (16384, {"mode": "1"}),
+               (20000, {"LJMD_N3_WG_WAVES": "2", "mode": "1"})):     # mixed precision beside LDS-combining workgroups
     mode = int(env.pop("mode", "0"))
     os.environ.update(env)
     p, r, v = synthetic.make_config(n, seed=3)
