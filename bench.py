@@ -561,9 +561,15 @@ def measure(args) -> None:
         # this rank's launch covers (its rows x all columns / 2)
         flops_per_launch = FLOP_PER_UNORDERED_PAIR * pairs / n_ranks
         achieved = flops_per_launch / (force_ms * 1e-3) / 1e12 if force_ms > 0 else 0.0
-        multi_cfg = {}
+        # per-rank figures of the timed steps, whichever way the ranks were driven (one rank: the same keys)
+        multi_cfg = {
+            "per_rank_ms": [round(q["pair_ms"] + q["geometry_ms"] + q["drift_ms"] + q["reduce_ms"], 4) for q in profs],
+            "position_exchange_ms": [round(q.get("pos_exchange_ms", 0.0), 4) for q in profs],
+            "force_exchange_ms": [round(q.get("force_exchange_ms", 0.0), 4) for q in profs],
+            "migrations": int(eng.migrations()),
+        }
         if n_ranks > 1:
-            multi_cfg = {
+            multi_cfg.update({
                 "launch_mode": mode,
                 "rccl_ranks_seen": eng.comm_size(),
                 "ownership": f"x-slabs of exactly n/G particles dealt by position on the devices (ljmd_migrate); migrations so far: {eng.migrations()}",
@@ -575,7 +581,7 @@ def measure(args) -> None:
                                       "start it: waiting for the slowest rank is included",
                 "force_exchange": os.environ.get("LJMD_FORCE_EXCHANGE", "reducescatter"),
                 "overlap_exchange": os.environ.get("LJMD_OVERLAP_EXCHANGE", "1"),
-            }
+            })
         line = {
             "metric": (f"md_steps_per_sec_n{n}_fp64" if args.mode == "fp64" else f"md_steps_per_sec_n{n}_mixed_fp32_far_pairs"),
             "value": steps_per_s, "unit": "steps/s", "n_gpus": n_ranks, "steps": args.steps,

@@ -262,6 +262,10 @@ def test_bench_two_processes_host_staged_exchange(tmp_path):
     assert len([ln for ln in out2.stdout.splitlines() if ln.strip()]) == 1          # stdout = the ONE JSON line
     assert line2["n_gpus"] == 2 and "HOST-STAGED" in line2["config"]["exchange"]
     assert line2["config"]["rccl_ranks_seen"] == 0                                   # no communicator in this rehearsal
+    for key in ("per_rank_ms", "position_exchange_ms", "force_exchange_ms"):         # one entry per rank, in every rung's line
+        assert len(line2["config"][key]) == 2, key
+    assert all(ms > 0 for ms in line2["config"]["per_rank_ms"]) and line2["config"]["migrations"] >= 0
+    assert len(line1["config"]["per_rank_ms"]) == 1 and line1["config"]["migrations"] == 0
     for key in ("etot_first", "etot_last"):
         a, b = line2["energy_check"][key], line1["energy_check"][key]
         assert abs(a - b) <= 1e-11 * abs(b), (key, a, b)
@@ -483,10 +487,13 @@ def test_config4_sharded_eight_ranks_n1048576(oracle):
     assert worst <= 1e-12
 
 
-def test_bench_ladder_rehearsal_on_one_card(tmp_path):
+@pytest.mark.parametrize("ladder", ["", "multi-host"])
+def test_bench_ladder_rehearsal_on_one_card(tmp_path, ladder):
     """bench.py --gpus 2 on this one-GPU box with every rank on device 0 (LJMD_BENCH_SHARE_DEVICE=1): RCCL refuses two
     ranks on one device, so the first two rungs of the launch ladder fail (for real, not by stand-ins) and the
-    peer-copy rung delivers the line -- watchdog, process-tree handling and the single-process worker end to end."""
+    peer-copy rung delivers the line -- watchdog, process-tree handling and the single-process worker end to end.
+    ladder = "multi-host": the last rung alone (pinned-host staging).  Either line carries the per-rank figures the
+    first multi-GPU session is read by (profiles/r04_multi_gpu_first_contact.md)."""
     import json
     import os
     import subprocess
@@ -494,16 +501,26 @@ def test_bench_ladder_rehearsal_on_one_card(tmp_path):
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env.update(LJMD_BENCH_SHARE_DEVICE="1")
+    if ladder:
+        env.update(LJMD_BENCH_LADDER=ladder)
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
                           "--particles", "32768", "--no-liquid"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and len([ln for ln in out.stdout.splitlines() if ln.strip()]) == 1
     cfg = lines[0]["config"]
-    assert cfg["launch_mode"] == "multi-copy" and "peer-to-peer" in cfg["exchange"]
-    assert [a["mode"] for a in cfg["ladder"]] == ["ranks-rccl", "multi-rccl", "multi-copy"]
-    assert [a["outcome"] for a in cfg["ladder"]][2] == "ok" and all(a["outcome"].startswith("exit") for a in cfg["ladder"][:2])
+    if ladder:
+        assert cfg["launch_mode"] == "multi-host" and "pinned host" in cfg["exchange"]
+        assert [(a["mode"], a["outcome"]) for a in cfg["ladder"]] == [("multi-host", "ok")]
+    else:
+        assert cfg["launch_mode"] == "multi-copy" and "peer-to-peer" in cfg["exchange"]
+        assert [a["mode"] for a in cfg["ladder"]] == ["ranks-rccl", "multi-rccl", "multi-copy"]
+        assert [a["outcome"] for a in cfg["ladder"]][2] == "ok" and all(a["outcome"].startswith("exit") for a in cfg["ladder"][:2])
     assert cfg["rccl_ranks_seen"] == 0 and len(cfg["pair_kernel_ms_per_rank"]) == 2
+    # the keys every rung's line carries (also at one GPU): whole step per rank, both exchanges, migrations so far
+    assert len(cfg["per_rank_ms"]) == len(cfg["position_exchange_ms"]) == len(cfg["force_exchange_ms"]) == 2
+    assert all(ms > 0 for ms in cfg["per_rank_ms"] + cfg["position_exchange_ms"] + cfg["force_exchange_ms"])
+    assert cfg["migrations"] >= 1                              # the deal by position at the start
     assert all(ms > 0 for ms in cfg["pair_kernel_ms_per_rank"] + cfg["position_exchange_ms_per_rank"] +
                cfg["force_exchange_ms_per_rank"])
     assert lines[0]["n_gpus"] == 2 and lines[0]["value"] > 0 and lines[0]["energy_check"]["rel_drift"] < 1e-3
