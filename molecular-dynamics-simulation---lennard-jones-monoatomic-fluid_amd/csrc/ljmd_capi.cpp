@@ -74,7 +74,7 @@ GeometryArgs geometry_args(ljmd_t *h)
     a.mask_far = h->d_mask_far;       // NULL unless mixed precision
     a.rsplit2 = h->r_split * h->r_split;
     a.pertile_images = env_int("LJMD_N3_PERTILE", 1) != 0 ? 1 : 0;
-    a.both_ties = h->half_ties ? 1 : 0;
+    a.both_ties = h->both_ties ? 1 : 0;
     return a;
 }
 
@@ -103,9 +103,11 @@ N3Args n3_args(ljmd_t *h)
     a.CS = h->CS;
     a.by_group = h->j_by_group;
     a.dchunk = h->dchunk;
+    a.uchunk = h->uchunk;
+    a.parts_log2 = h->parts == 4 ? 2 : h->parts == 2 ? 1 : 0;
     a.xcd_remap = 0;
-    a.inline_class = (h->fuse_tail && h->rt == 1 && h->wg_waves == 1) ? 1 : 0;
-    a.half_ties = h->half_ties ? 1 : 0;
+    a.inline_class = (h->fuse_tail && h->rt <= 2 && h->wg_waves == 1) ? 1 : 0;
+    a.both_ties = h->both_ties ? 1 : 0;
     a.rc2_skin = h->rc2 * (1.0 + 1e-10);
     a.energy = h->want_energy ? 1 : 0;
     a.RT = h->rt;
@@ -924,8 +926,8 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         int rt = env_int("LJMD_N3_ROW_TILES", 0);
         if (mixed_mode) rt = kRowTiles;                       // the fp32 far kernel is built for 4
         if (rt != 1 && rt != 2 && rt != kRowTiles) {
-            // measured (profiles/r02_row_tiles_sweep.txt, with the batched reciprocal): 4 wins from n = 65536 up,
-            // 2 for 16384..32768, 1 below
+            // measured (profiles/r04_unit_sweep.txt; work items cut down to single passes, N3Args::uchunk): 4 wins from
+            // n = 32768 up, 2 from 6144 (two-launch step included), 1 below
             auto items = [&](int cand) { const long ngo = h->TB / cand; return ngo * ((long)h->G * ngo / 2 + 1); };
             rt = items(kRowTiles) >= kN3ItemsFor4 ? kRowTiles : items(2) >= kN3ItemsFor2 ? 2 : 1;
         }
@@ -949,39 +951,50 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         }
         if (rt != kRowTiles || h->NGo < 16 * wg) wg = 1;
         h->wg_waves = wg;
-        // slab_j: the blocks of a column tile lie together (N3Args::slab_j)
+        // parts per pass (N3Args::parts_log2): 2 or 4 cut the 64 rotation steps of a pass into independent work of 32 / 16 steps
+        // -- more, smaller work items for the systems that cannot fill 1024 SIMDs with whole passes.  One wave per workgroup
+        // only; not in the mixed mode (the far kernel walks whole passes over the same slices).
+        int parts = env_int("LJMD_N3_PARTS", 0);
+        if (parts != 1 && parts != 2 && parts != 4) parts = 1;
+        if (wg != 1 || mixed_mode) parts = 1;
+        h->parts = parts;
+        // the tie d = NG / 2 worked from both sides (N3Args::both_ties): equal work for every row group where there are few
+        // of them; one rank, one wave per workgroup, fp64 mode
+        h->both_ties = wg == 1 && n_ranks == 1 && !mixed_mode && h->NG <= kBothTiesMaxGroups && env_int("LJMD_N3_BOTH_TIES", 1) != 0;
+        // slab_j: the blocks of a column tile lie together (N3Args::slab_j), `parts` of them per (row group | offset)
         h->j_by_group = (h->G > 1 || h->NG % wg != 0) ? 1 : 0;
-        h->CS = h->j_by_group ? (h->NGo + wg - 1) / wg : (h->Dmax + wg - 1) / wg + 1;
+        h->CS = (h->j_by_group ? (h->NGo + wg - 1) / wg : (h->Dmax + wg - 1) / wg + 1) * parts;
         h->CS2 = h->G > 1 ? h->NGo : h->Dmax + 1;              // far pass: one wave per workgroup
         const int n3_min = env_int("LJMD_N3_MIN_N", 4096);
         // (rc within 1e-9 of L/2 -- the reference accepts rc_over_L up to 0.5 and rejects only rc >= L/2 -- takes the exact
         //  generic kernel, which has no Newton-3 form: a multi-rank run then needs no force exchange at all, and every
         //  rank must know that when it allocates)
         h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min && (h->G == 1 || h->rc_allows_fast);
-        const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", 131072));
-        int ns = (target_waves + h->NGo - 1) / h->NGo;
+        // work items = (row group, slice of its units), N3Args::uchunk.  Large systems: slices of whole offsets (dchunk),
+        // ~target_waves items; a system with fewer (row group, offset) pairs than that is cut finer, down to one unit
+        // (one pass, or one part of a pass) per item.
         const int n_off = h->Dmax + h->wg_waves;          // offsets a workgroup walks (relative to its first row group)
-        ns = std::max(1, std::min(ns, n_off));
+        const int n_units = n_off * rt * parts;
+        const bool plenty = (long)h->NGo * n_off >= kN3LargeItems;
+        const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", plenty ? 131072 : kN3MidTargetItems));
+        const int ns_wanted = (target_waves + h->NGo - 1) / h->NGo;
+        int ns = std::max(1, std::min(ns_wanted, n_off));
         // small single-rank systems: at most 4096 work items, so that the step record is folded by ONE block whichever
         // way the step is launched (the fused step kernel keeps finalize_body's summation order, not fold_partials')
-        const bool small_single = n_ranks == 1 && n <= 8192 && rt == 1;
-        if (small_single) ns = std::max(1, std::min(ns, 4096 / std::max(1, h->NGo)));
+        const bool small_single = n_ranks == 1 && n <= 8192 && rt <= 2;
+        const int ns_cap = small_single ? std::max(1, 4096 / std::max(1, h->NGo)) : n_units;
+        ns = std::min(ns, ns_cap);
         h->dchunk = (n_off + ns - 1) / ns;
-        h->nslab_n = (n_off + h->dchunk - 1) / h->dchunk;
-        // one-tile row groups on one rank: work items of EQUAL cost (N3Args::half_ties).  A row tile has (NG - 1) / 2 full
-        // offsets plus one unit made of its self pass and its half of the tie; dchunk = units per item.
-        h->half_ties = h->use_n3 && rt == 1 && wg == 1 && n_ranks == 1 && env_int("LJMD_N3_HALF_TIES", 1) != 0;
-        if (h->half_ties) {
-            const int units = (h->NG - 1) / 2 + 1;
-            int nsl = std::max(1, std::min((target_waves + h->NGo - 1) / h->NGo, units));
-            if (small_single) nsl = std::max(1, std::min(nsl, 4096 / std::max(1, h->NGo)));
-            h->dchunk = (units + nsl - 1) / nsl;
-            h->nslab_n = (units + h->dchunk - 1) / h->dchunk;
+        h->uchunk = h->dchunk * rt * parts;
+        if (!mixed_mode && (ns_wanted > n_off || parts > 1)) {          // finer than whole offsets
+            const int nsu = std::max(1, std::min(std::min(ns_wanted, ns_cap), n_units));
+            h->uchunk = (n_units + nsu - 1) / nsu;
         }
+        h->nslab_n = (n_units + h->uchunk - 1) / h->uchunk;
     }
     // two launches per step for small single-rank systems (tile_tail_kernel; ljmd_engine.h: fuse_tail)
     h->fuse_tail = h->fuse_small && env_int("LJMD_FUSE_TAIL", 1) != 0 && n_ranks == 1 && n <= 8192 && h->rc_allows_fast &&
-                   precision_mode == LJMD_PRECISION_FP64 && (!h->use_n3 || (h->rt == 1 && h->wg_waves == 1));
+                   precision_mode == LJMD_PRECISION_FP64 && (!h->use_n3 || (h->rt <= kFuseTailMaxRowTiles && h->wg_waves == 1));
     h->defer_record = env_int("LJMD_FUSE_DEFER_RECORD", 1) != 0;
     const bool mixed = precision_mode == LJMD_PRECISION_FP32_FORCE;
     if (mixed && (!h->use_n3 || n < kMixedMinN)) {
@@ -1020,7 +1033,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, n_blk, h->stream));
             LJMD_HIP(h, hipMalloc(&h->d_desc, (size_t)h->NGo * h->T * sizeof(unsigned)));
             // cluster passes (ljmd_kernels.hip: n3_cluster_pass): 4-tile row groups, one wave per workgroup
-            if (h->rt == kRowTiles && h->wg_waves == 1 && env_int("LJMD_N3_CLUSTERS", 1) != 0)
+            if (h->rt == kRowTiles && h->wg_waves == 1 && h->parts == 1 && env_int("LJMD_N3_CLUSTERS", 1) != 0)
                 LJMD_HIP(h, hipMalloc(&h->d_desc2, (size_t)h->NGo * h->T * 8 * sizeof(float)));
             LJMD_HIP(h, hipMalloc(&h->d_pos_tc, P3 * h->G));
         }

@@ -30,8 +30,12 @@ constexpr unsigned kRingCap = 4096;     // per-step partial records kept on the 
 constexpr int kTargetWorkgroups = 2048; // >> 256 CUs (8 per CU) for the pair kernels
 constexpr int kXcdMinGroups = 256;      // row groups per rank from which the XCD-aware work mapping is used (neutral below)
 constexpr int kMixedMinN = 16384;       // smallest system the mixed-precision mode accepts
-constexpr long kN3ItemsFor4 = 30000;    // Newton-3 work items (row groups x offsets) a rank needs before 4 ...
-constexpr long kN3ItemsFor2 = 6144;     // ... or 2 tiles per row group pay off
+constexpr long kN3ItemsFor4 = 6000;     // (row group, offset) pairs a rank needs before 4 (n >= 32768 on one rank) ...
+constexpr long kN3ItemsFor2 = 1000;     // ... or 2 (n >= 6144) tiles per row group pay off: profiles/r04_unit_sweep.txt
+constexpr long kN3LargeItems = 131072;  // (row group, offset) pairs of a rank from which work items are slices of whole offsets
+constexpr int kN3MidTargetItems = 32768;   // work items aimed at below that (units of one pass, or of a part of one)
+constexpr int kBothTiesMaxGroups = 128; // row groups up to which the tie d = NG / 2 is worked from both sides
+constexpr int kFuseTailMaxRowTiles = 2; // tiles per row group up to which small systems take the two-launch step
 constexpr int kMaxProfiledLaunches = 4096;
 constexpr int kEventsPerLaunch = 9;
 
@@ -138,7 +142,8 @@ struct ljmd {
     // Newton-3 kernel (single rank): NG row groups, offsets 0..Dmax in nslab_n slices of dchunk
     bool use_n3 = false;
     int wg_waves = 1;                 // LJMD_N3_WG_WAVES: row groups (waves) per pair-kernel workgroup (1, 2, 4)
-    bool half_ties = false;           // one-tile row groups on one rank: equal-cost work items (N3Args::half_ties)
+    bool both_ties = false;           // one rank, one wave per workgroup: the tie d = NG / 2 is worked from both sides (N3Args::both_ties)
+    int parts = 1, uchunk = 0;        // parts per pass (LJMD_N3_PARTS: 1, 2, 4) and units per work item (N3Args::uchunk)
     // two launches per step, record fold off the critical path (tile_tail_kernel): the step's record is folded by the NEXT
     // tail launch of the batch; the workgroup partials and per-tile v^2 sums it reads alternate between two buffers
     bool fold_pending = false, defer_record = true;

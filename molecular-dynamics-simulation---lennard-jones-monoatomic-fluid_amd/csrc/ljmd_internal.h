@@ -71,14 +71,16 @@ struct N3Args {
     int NG, NGo, Dmax;      // row groups in total / owned by this rank (NGo = TB / RT, NG = G * NGo)
     int CS, by_group;       // slab_j layout (above)
     int RT;                 // tiles per row group: 4 for large systems, 1 or 2 to give small ones enough work items
-    int dchunk;             // offsets d per grid.y slice
+    int dchunk;             // fp32 far kernel: offsets d per grid.y slice
+    int uchunk;             // pair_n3_kernel: UNITS per grid.y slice.  Unit u of a row group = (e * RT + l) * H + part: offset e,
+                            // column tile l of the group there, part of the pass; = dchunk * RT * H unless the system is cut finer
+    int parts_log2;         // H = 1 << parts_log2 = 1, 2 or 4 parts of 64 / H rotation steps per pass (one wave per workgroup
+                            // only); slab_j then holds H blocks per (column tile, row group or offset), CS counts them all
     int energy;             // 0: forces only -- the energy sums are not accumulated and the workgroup partials are NaN
     int xcd_remap;          // C > 0: XCD-aware mapping, chunks of C consecutive row groups per XCD (gridDim.x % (8 C) == 0)
-    int inline_class;       // RT = 1, one wave per workgroup: the waves compute their pass descriptors themselves (desc unused)
-    int half_ties;          // RT = 1, one wave per workgroup, one rank: slice 0 of a row tile = the tile against itself + (NG
-                            // even) its half of the tie d = NG / 2, both as 32-step half passes, then the offsets
-                            // 1 .. dchunk - 1; slice by >= 1 = the offsets by * dchunk .. by * dchunk + dchunk - 1:
-                            // every work item is dchunk full passes (ljmd_kernels.hip: n3_half_pass)
+    int inline_class;       // RT <= 2, one wave per workgroup: the waves compute their pass descriptors themselves (desc unused)
+    int both_ties;          // one wave per workgroup, one rank: the tie d = NG / 2 (NG even) is worked from both sides, the
+                            // steps 0 .. 31 by the lower row group and 1 .. 32 by the upper one (ljmd_kernels.hip: tile_of)
     double L, invL, rc2;
     double rc2_skin;        // rc^2 (1 + 1e-10) of the tile-pair test (GeometryArgs::rc2_skin), for inline_class
 };
@@ -138,7 +140,7 @@ struct GeometryArgs {
     double L, invL, rc2_skin;   // rc^2 * (1 + 1e-10): skip only when provably outside
     double rsplit2;         // r_split^2
     int pertile_images;     // tile_class: row tiles may take their own periodic image on a single general axis (LJMD_N3_PERTILE)
-    int both_ties;          // tile_class: the tie d = NG / 2 is visited from both sides (N3Args::half_ties)
+    int both_ties;          // tile_class: the tie d = NG / 2 is visited from both sides (N3Args::both_ties)
 };
 
 struct RdfArgs {

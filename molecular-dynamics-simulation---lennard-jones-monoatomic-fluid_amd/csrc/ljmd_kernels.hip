@@ -456,17 +456,22 @@ template <int RT, int NU, bool MASKED, bool INNER, bool BATCH = false, bool ENER
 __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const double (&yi)[RT],
                                                  const double (&zi)[RT], double (&ax)[RT],
                                                  double (&ay)[RT], double (&az)[RT],
-                                                 double xj, double yj, double zj, const double *park, unsigned mb,
+                                                 const double *park, int ns, unsigned mb,
                                                  double L, double invL, double rc2, double sx, double sy, double sz,
                                                  double &jx, double &jy, double &jz, double &s12, double &s6)
 {
     static_assert(!BATCH || (!MASKED && (RT == 2 || RT == 4)), "batched reciprocal: all row tiles, 2 or 4 of them");
-    // park = &lds[lane]: entry (lane + 64 - s), s = 0 is the lane's own particle (already in xj, yj, zj)
-    double nx = xj, ny = yj, nz = zj;
-#pragma unroll LJMD_N3_UNROLL
-    for (int s = 0; s < kTile; ++s) {
+    static_assert(kTile / 4 % LJMD_N3_UNROLL == 0, "a quarter pass is a whole number of unrolled bodies");
+    // The rotation steps s0 .. s0 + ns - 1 of the pass (a whole pass: 0 .. 63; a PART of one, N3Args::parts: a half or a
+    // quarter of them; ns is a multiple of the unroll count).  park = &lds[lane - s0]: entry (lane + 64 - s0 - s) is the
+    // particle that step s0 + s brings to the lane (s0 + s = 0: the lane's own).
+    double xj, yj, zj;
+    double nx = park[kTile], ny = park[kLdsAxis + kTile], nz = park[2 * kLdsAxis + kTile];
+    for (int sb = 0; sb < ns; sb += LJMD_N3_UNROLL, park -= LJMD_N3_UNROLL) {
+#pragma unroll
+    for (int s = 0; s < LJMD_N3_UNROLL; ++s) {
         xj = nx; yj = ny; zj = nz;
-        nx = park[kTile - 1 - s];                       // next step's particle; the last prefetch (entry lane) is unused
+        nx = park[kTile - 1 - s];                       // next step's particle; the last prefetch of a part is unused
         ny = park[kLdsAxis + kTile - 1 - s];
         nz = park[2 * kLdsAxis + kTile - 1 - s];
         if constexpr (BATCH) {
@@ -494,6 +499,7 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const d
                                               ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
         }
         jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
+    }
     }
 }
 
@@ -790,14 +796,16 @@ __device__ __forceinline__ void n3_cluster_pass(const N3Args &a, int lane, int A
     }
 }
 
-// One column tile against the wave's RT row tiles: the 64 rotation steps in the loop variant the pass descriptor names.
-// The tile's positions are loaded here (one particle per lane) and parked in LDS.
+// One column tile against the wave's RT row tiles: the rotation steps s0 .. s0 + ns - 1 (a whole pass: 0 .. 63) in the loop
+// variant the pass descriptor names.  The tile's positions are loaded here (one particle per lane) and parked in LDS.
+// The column-side sums start at zero and rotate one lane per step: after the last step lane l holds those of column slot
+// l - s_end (s_end = the steps of the pass that lie behind it: 64 brings every particle home).
 template <int RT, int W, bool ENERGY>
-__device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, int d, int l, unsigned mb, unsigned desc,
-                                             const double (&xi)[RT],
+__device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, int d, int l, int s0, int ns, unsigned mb,
+                                             unsigned desc, const double (&xi)[RT],
                                              const double (&yi)[RT], const double (&zi)[RT], double (&ax)[RT],
                                              double (&ay)[RT], double (&az)[RT], double *parked,
-                                             double &jx, double &jy, double &jz, double &s12, double &s6)
+                                             double &jx, double &jy, double &jz, int &s_end, double &s12, double &s6)
 {
     const size_t P = a.P;
     const int gj = (a.G == 1) ? 0 : c / a.TB;          // rank block holding the column tile
@@ -811,27 +819,8 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
     const double sy = (double)((int)((desc >> 14) & 7u) - 2) * a.L;
     const double sz = (double)((int)((desc >> 17) & 7u) - 2) * a.L;
 
-    if (d == 0 && ((mb >> l) & 1u)) {
-        // the column tile is one of the wave's own row tiles: tile l against itself
-        for (int s = 0; s < kTile; ++s) {
-#pragma unroll
-            for (int k = 0; k < RT; ++k) {
-                if (!((mb >> k) & 1u)) continue;
-                if (k == l) {
-                    if (s >= 1 && s <= 32)
-                        pair_n3<true, 7, false, ENERGY>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2,
-                                         s < 32 || lane < 32, 0.0, 0.0, 0.0, ax[k], ay[k], az[k], jx,
-                                         jy, jz, s12, s6);
-                } else {
-                    pair_n3<false, 7, false, ENERGY>(xi[k], yi[k], zi[k], xj, yj, zj, a.L, a.invL, a.rc2, true, 0.0,
-                                      0.0, 0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
-                }
-            }
-            xj = dpp_rotate(xj); yj = dpp_rotate(yj); zj = dpp_rotate(zj);
-            jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
-        }
-        return;
-    }
+    // the column tile is one of the wave's own row tiles (tile l against itself): the general minimum image, no fold
+    const bool diag = d == 0 && ((mb >> l) & 1u);
     // A common image of the whole tile pair is subtracted from the column tile ONCE, here, instead of from every
     // pair's difference: d = xi - (xj + nL).  Three additions per pass replace one subtraction per pair and imaged
     // axis, and the loop variants with a common image collapse into the one without (nu 16, 17, 18, 0 -> 8).
@@ -839,7 +828,7 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
     // minimum-image correction (geometry_pbc.f90:86): the same order of error (<= 2 ulp(L)), not the same bits.
     // An axis without a common image STRADDLES (nu 27, 28, 29: that axis alone; 30: two or three of them): the half-box
     // distance goes into the column tile as well and the loop runs the straddle form (pair_disp).
-    const bool general_all = nu == 7;
+    const bool general_all = nu == 7 || diag;
     int loop = 7;
     double hx = 0.0, hy = 0.0, hz = 0.0;                 // half-box constants of the straddle forms
     if (!general_all) {
@@ -862,12 +851,38 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
         parked[q * kLdsAxis + kTile + lane] = val;
     }
     wave_lds_sync<W>();
+    if (diag) {
+        // tile l against itself on the steps 1 .. 31 and the lower half of step 32 (each unordered pair once), against the
+        // group's earlier row tiles k < l on every step.  With one tile per group nothing lies beyond step 32.
+        const int t0 = RT == 1 ? max(s0, 1) : s0, t1 = RT == 1 ? min(s0 + ns, kTile / 2 + 1) : s0 + ns;
+        const double *q0 = parked + lane + kTile;       // entry lane + 64 - s
+        for (int s = t0; s < t1; ++s) {
+            const double cx = q0[-s], cy = q0[kLdsAxis - s], cz = q0[2 * kLdsAxis - s];
+#pragma unroll
+            for (int k = 0; k < RT; ++k) {
+                if (!((mb >> k) & 1u)) continue;
+                if (k == l) {
+                    if (s >= 1 && s <= kTile / 2)
+                        pair_n3<true, 7, false, ENERGY>(xi[k], yi[k], zi[k], cx, cy, cz, a.L, a.invL, a.rc2,
+                                         s < kTile / 2 || lane < kTile / 2, 0.0, 0.0, 0.0, ax[k], ay[k], az[k], jx,
+                                         jy, jz, s12, s6);
+                } else {
+                    pair_n3<false, 7, false, ENERGY>(xi[k], yi[k], zi[k], cx, cy, cz, a.L, a.invL, a.rc2, true, 0.0,
+                                      0.0, 0.0, ax[k], ay[k], az[k], jx, jy, jz, s12, s6);
+                }
+            }
+            jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
+        }
+        s_end = max(t0, t1);
+        return;
+    }
+    s_end = s0 + ns;
 #define LJMD_LOOP(NU_, MASKED_, INNER_)                                                                      \
-    column_tile_loop<RT, NU_, MASKED_, INNER_, false, ENERGY>(xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL,  \
+    column_tile_loop<RT, NU_, MASKED_, INNER_, false, ENERGY>(xi, yi, zi, ax, ay, az, parked + lane - s0, ns, mb, a.L, a.invL,  \
                                                   a.rc2, hx, hy, hz, jx, jy, jz, s12, s6)
 #define LJMD_LOOP_ALL(NU_, INNER_)                                                                           \
     column_tile_loop<RT, NU_, false, INNER_, (RT == 2 || RT == 4) && LJMD_BATCH_RCP, ENERGY>(                              \
-        xi, yi, zi, ax, ay, az, xj, yj, zj, parked + lane, mb, a.L, a.invL, a.rc2, hx, hy, hz, jx, jy, jz, s12, s6)
+        xi, yi, zi, ax, ay, az, parked + lane - s0, ns, mb, a.L, a.invL, a.rc2, hx, hy, hz, jx, jy, jz, s12, s6)
     // all row tiles active AND no padding slot anywhere in the tile pair: the unmasked loop with the batched
     // reciprocal; otherwise the masked loop (correct for any mb; a NaN padding slot must not enter a product)
     const bool all4 = mb == ((1u << RT) - 1u) && (full || !LJMD_BATCH_RCP);
@@ -889,77 +904,6 @@ __device__ __forceinline__ void n3_tile_pass(const N3Args &a, int lane, int c, i
 #undef LJMD_LOOP
 }
 
-// HALF passes of the one-tile-per-group kernel (N3Args::half_ties, small single-rank systems): 32 rotation steps instead
-// of 64, for the two kinds of pass that are not a full 64 x 64 tile pair.
-//   * a tile against itself: steps 1 .. 31 and the lower half of step 32 (each unordered pair once);
-//   * the tie, row tile A against column tile B = A + NG / 2 (NG even): instead of one side owning the whole pass and
-//     the other idling, A < B takes the steps 0 .. 31 against B and B the steps 1 .. 32 against A.  Step s of (A, B)
-//     pairs row i with column i - s; step s' of (B, A) pairs row j with column j - s', i.e. the shift -s' of the first
-//     pass: the two halves cover every shift mod 64 exactly once.
-// Every (row tile, offset slice) work item is then a whole number of full passes -- at n = 4096 exactly 2048 equal items
-// for 1024 SIMDs, where 2112 unequal ones left 64 SIMDs with three (profiles/r04_small_n_wave_trace.txt).
-// The column-side sums stop half way round the wave: lane l ends with the sums of column slot l - t1 and stores them
-// there.  One loop for all image classes: the straddle form on all axes (half-box constant 0 on a plain axis), or the
-// general minimum image (self pass; descriptor class 7).
-template <bool ENERGY>
-__device__ __forceinline__ void n3_half_pass(const N3Args &a, int lane, int c, bool self, bool first_half, unsigned desc,
-                                             double xi, double yi, double zi, double &ax, double &ay, double &az,
-                                             double *parked, double *out /* slab_j block */, double &s12, double &s6)
-{
-    const size_t P = a.P;
-    const double *cb = a.pos + (size_t)c * kTile + lane;           // (single rank)
-    double xj = cb[0], yj = cb[P], zj = cb[2 * P];
-    const int nu = (int)((desc >> 4) & 31u);
-    const bool general = self || nu == 7;
-    double hx = 0.0, hy = 0.0, hz = 0.0;
-    if (!general) {                                                 // the folds of n3_tile_pass
-        xj += (double)((int)((desc >> 11) & 7u) - 2) * a.L;
-        yj += (double)((int)((desc >> 14) & 7u) - 2) * a.L;
-        zj += (double)((int)((desc >> 17) & 7u) - 2) * a.L;
-        if (nu >= 27 && nu <= 30) {
-            const double half = 0.5 * a.L;
-            const unsigned st = (desc >> 22) & 7u, sg = (desc >> 25) & 7u;
-            if (st & 1u) { hx = half; xj += (sg & 1u) ? half : -half; }
-            if (st & 2u) { hy = half; yj += (sg & 2u) ? half : -half; }
-            if (st & 4u) { hz = half; zj += (sg & 4u) ? half : -half; }
-        }
-    }
-    wave_lds_sync<1>();                                             // the previous tile's reads are done
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const double val = q == 0 ? xj : q == 1 ? yj : zj;
-        parked[q * kLdsAxis + lane] = val;
-        parked[q * kLdsAxis + kTile + lane] = val;
-    }
-    wave_lds_sync<1>();
-    const int t0 = (self || !first_half) ? 1 : 0, t1 = t0 + kTile / 2;
-    double jx = 0.0, jy = 0.0, jz = 0.0;
-    // entry lane + 64 - t is the particle step t brings; q0[31 - s] with immediate offsets, read one step ahead
-    const double *q0 = parked + lane + kTile - t0 - (kTile / 2 - 1);
-    double nx = q0[kTile / 2 - 1], ny = q0[kLdsAxis + kTile / 2 - 1], nz = q0[2 * kLdsAxis + kTile / 2 - 1];
-#pragma unroll 8
-    for (int s = 0; s < kTile / 2; ++s) {
-        const int t = t0 + s;
-        const double cx = nx, cy = ny, cz = nz;
-        const int nxt = s + 1 < kTile / 2 ? kTile / 2 - 2 - s : 0;  // (the last prefetch is unused)
-        nx = q0[nxt];
-        ny = q0[kLdsAxis + nxt];
-        nz = q0[2 * kLdsAxis + nxt];
-        const bool ok = !self || t < kTile / 2 || lane < kTile / 2;
-        if (general)
-            pair_n3<true, 7, false, ENERGY>(xi, yi, zi, cx, cy, cz, a.L, a.invL, a.rc2, ok, 0.0, 0.0, 0.0, ax, ay, az, jx, jy, jz,
-                                            s12, s6);
-        else
-            pair_n3<true, 40, false, ENERGY>(xi, yi, zi, cx, cy, cz, a.L, a.invL, a.rc2, ok, hx, hy, hz, ax, ay, az, jx, jy, jz,
-                                             s12, s6);
-        jx = dpp_rotate(jx); jy = dpp_rotate(jy); jz = dpp_rotate(jz);
-    }
-    const int slot = (lane - t1) & (kTile - 1);                     // whose sums this lane carries after t1 rotations
-    out[slot] = jx;
-    out[kTile + slot] = jy;
-    out[2 * kTile + slot] = jz;
-}
-
 // (defined with the geometry pre-pass below)
 template <int RT>
 __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, double rc2, int S, int Al, int c,
@@ -977,7 +921,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
     // XCD has its own L2).  With the plain mapping the row groups A, A+1, ... that read the same column tiles (B = A + d
     // for the few d of a slice) sit on 8 different XCDs and every one of them fetches the tile through the fabric.
     unsigned bx = blockIdx.x, by = blockIdx.y;
-    if (a.xcd_remap) {                                         // host guarantees gridDim.x % (8 * chunk) == 0
+    if (a.xcd_remap) {                              // host guarantees gridDim.x % (8 * chunk) == 0
         // an XCD takes chunks of `xcd_remap` consecutive row groups, the chunks dealt round-robin over the XCDs: the
         // row groups inside a chunk share their column tiles through the XCD's L2, while every XCD still sees the same
         // statistical mix of heavy and light work items at any time (ONE contiguous eighth per XCD measured 10 %
@@ -1012,44 +956,60 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         ax[k] = ay[k] = az[k] = 0.0;
     }
 
-    // e = offset of the column group from the workgroup's FIRST row group; wave w is at its own offset d = e - w.
-    // Every wave of the workgroup runs the same e and l trip counts (one barrier per column tile when W > 1).
-    const int e0 = (int)by * a.dchunk;
-    const int e1 = min(e0 + a.dchunk, a.Dmax + W);
+    // UNITS of work.  A row group walks the offsets e = 0 .. Dmax (+ W - 1: e is counted from the workgroup's FIRST row
+    // group, wave w is at its own offset d = e - w), at every offset the RT column tiles l of the group there, and every
+    // such pass in H = 1 << parts_log2 PARTS of 64 / H rotation steps: unit u = (e * RT + l) * H + part.  A work item
+    // (grid.y slice) takes `uchunk` consecutive units.  Large systems: H = 1 and uchunk = a few offsets' worth, one item is
+    // several whole passes; small and middle-sized ones cut finer -- down to a quarter pass per item -- so that the 1024
+    // SIMDs get several items each (profiles/r04_mid_n_rates.txt).
+    // Every wave of the workgroup runs the same units (one barrier per column tile when W > 1; then H = 1).
+    const int hl = W == 1 ? a.parts_log2 : 0, H = 1 << hl;
+    const int u0 = (int)by * a.uchunk;
+    const int nt = max(0, min(a.uchunk, (((a.Dmax + W) * RT) << hl) - u0));
+    // The tie d = NG / 2 (NG even) is one pass for TWO row groups.  both_ties (one rank, W = 1): instead of one side owning
+    // the whole pass and the other idling, A < B takes the steps 0 .. 31 against B and B the steps 1 .. 32 against A.  Step
+    // s of (A, B) pairs row i with column i - s; step s' of (B, A) pairs row j with column j - s', i.e. the shift -s' of the
+    // first pass: the two halves cover every shift mod 64 exactly once, and the work of the row groups is equal.
+    const bool both = W == 1 && a.both_ties != 0;
 
-    // tile t = (e - e0) * RT + l of this work item: its column tile c, offset d, slab block, and the mask bits of the
-    // wave's RT row tiles (0 = nothing to do: not owned, or every row tile proven outside the cutoff)
-    // half_ties (RT = 1, one wave per workgroup, one rank): slice 0 = the tile against itself, the tie if NG is even (two
-    // half passes: n3_half_pass), then the offsets 1 .. dchunk - 1; slice by >= 1 = the offsets by * dchunk .. + dchunk - 1
-    const bool half_ties = RT == 1 && W == 1 && a.half_ties != 0;
-    const int n_special = half_ties ? 1 + ((a.NG & 1) == 0 && a.NG > 1 ? 1 : 0) : 0;
-    auto tile_of = [&](int t, int &c, int &d, int &l, size_t &blk, unsigned &desc) -> unsigned {
-        int e = e0 + t / RT;
-        if (half_ties) e = by == 0 ? (t == 0 ? 0 : t < n_special ? a.NG / 2 : t - n_special + 1) : e0 + t;
-        l = t - (t / RT) * RT;
+    // unit t of this work item: its column tile c, offset d, steps s0 .. s0 + ns - 1, slab block, and the mask bits of
+    // the wave's RT row tiles (0 = nothing to do: not owned, or every row tile proven outside the cutoff)
+    auto tile_of = [&](int t, int &c, int &d, int &l, int &s0, int &ns, size_t &blk, unsigned &desc) -> unsigned {
+        const int u = u0 + t, pass = u >> hl, hp = u - (pass << hl);
+        const int e = pass / RT;
+        l = pass - e * RT;
         d = e - wv;
-        // (half_ties: the tie is reached through slice 0 only, never as a regular offset)
-        const bool valid = active && d >= 0 && d <= a.Dmax && (!half_ties || (by == 0 && t < n_special) || 2 * d < a.NG);
+        const bool valid = active && d >= 0 && d <= a.Dmax;
         int B = A0 + e;
         if (B >= a.NG) B -= a.NG;
-        const bool owned = valid && ((d == 0) || (2 * d < a.NG) || (2 * d == a.NG && (A < B || (half_ties && by == 0 && t < n_special))));
+        const bool tie = 2 * d == a.NG;
+        bool work = valid && ((d == 0) || (2 * d < a.NG) || (tie && (A < B || both)));
         c = RT * B + l;                                 // column tile (global)
-        blk = (size_t)c * a.CS + (size_t)(a.by_group ? (int)bx : e / W);   // N3Args::slab_j
+        blk = (size_t)c * a.CS + (size_t)(((a.by_group ? (int)bx : e / W) << hl) + hp);   // N3Args::slab_j
+        ns = kTile >> hl;
+        s0 = hp * ns;
+        if (tie && both) {
+            const int side = A < B ? 0 : 1;
+            if (H == 1) { s0 = side; ns = kTile / 2; }
+            else if (2 * hp < H) s0 += side;
+            else work = false;
+        }
+        if (RT == 1 && d == 0 && s0 > kTile / 2) work = false;     // a tile against itself ends with step 32
         unsigned mb = 0;
         desc = 0;
-        if (owned) {
+        if (work) {
             // wave-uniform by construction: keep it in SGPRs so that the per-row-tile tests are scalar branches
-            if constexpr (RT == 1 && W == 1) {
+            if constexpr (RT <= 2 && W == 1) {
                 // small single-rank systems (N3Args::inline_class): the wave works its pass descriptor out itself
                 // -- the same function tile_class_kernel runs -- and the step saves a launch
                 if (a.inline_class) {
                     GeometryArgs ga;
                     ga.pos = nullptr; ga.bbox = const_cast<double *>(a.bbox); ga.pos_tc = nullptr; ga.mask = nullptr; ga.mask_far = nullptr;
-                    ga.P = a.P; ga.G = a.G; ga.rank = a.rank; ga.TB = a.TB; ga.T = a.T; ga.W = a.W; ga.RT = 1;
+                    ga.P = a.P; ga.G = a.G; ga.rank = a.rank; ga.TB = a.TB; ga.T = a.T; ga.W = a.W; ga.RT = RT;
                     ga.L = a.L; ga.invL = a.invL; ga.rc2_skin = a.rc2_skin; ga.rsplit2 = 0.0; ga.pertile_images = 0;
-                    ga.both_ties = a.half_ties;
+                    ga.both_ties = a.both_ties;
                     unsigned dsc = 0;
-                    (void)tile_class<1>(ga, a.invL, a.rc2, a.S, Al, c, dsc, nullptr, nullptr);
+                    (void)tile_class<RT>(ga, a.invL, a.rc2, a.S, Al, c, dsc, nullptr, nullptr);
                     desc = (unsigned)__builtin_amdgcn_readfirstlane((int)dsc);
                 } else {
                     desc = (unsigned)__builtin_amdgcn_readfirstlane((int)a.desc[(size_t)Al * a.T + c]);
@@ -1062,19 +1022,17 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
         }
         return mb;
     };
-    const int d_full = (a.NG - 1) / 2;                         // offsets 1 .. d_full are full passes
-    const int nt = half_ties ? (by == 0 ? n_special + min(a.dchunk - 1, d_full) : max(0, min(a.dchunk, d_full + 1 - e0)))
-                             : (e1 - e0) * RT;
 
     {
         double *parked = parked_all[wv];
         int buf = 0;
         for (int t = 0; t < nt; ++t) {
-            int c, d, l;
+            int c, d, l, s0, ns;
             size_t blk;
             unsigned desc;
-            const unsigned mb = tile_of(t, c, d, l, blk, desc);
+            const unsigned mb = tile_of(t, c, d, l, s0, ns, blk, desc);
             const bool have = mb != 0;
+            int s_end = kTile;                                 // column slot of lane l's sums after the pass: l - s_end
 #ifdef LJMD_WAVE_TRACE
             if (t == 0) tr1 = trace_now();
             tr_heavy += have ? 1u : 0u;
@@ -1097,21 +1055,16 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
                 // column tiles a work item walks (LJMD_N3_TARGET_WAVES, n), 2 additions per 64 rotation steps
                 double p12 = 0.0, p6 = 0.0;
                 if constexpr (W == 1 && RT == kRowTiles) {
-                    if ((desc >> 20) & 1u) {                       // boundary pass: cluster by cluster (tile_class_kernel)
+                    // boundary pass: cluster by cluster (tile_class_kernel) -- whole passes only
+                    if (((desc >> 20) & 1u) && ns == kTile) {
                         n3_cluster_pass<RT, ENERGY>(a, lane, Al, c, mb, desc, xi, yi, zi, ax, ay, az, parked,
                                                     a.slab_j + blk * (3 * kTile), p12, p6);
                         stored = true;
                     }
                 }
-                if constexpr (RT == 1 && W == 1) {
-                    if (half_ties && (d == 0 || 2 * d == a.NG)) {  // the tile against itself, or one half of the tie
-                        n3_half_pass<ENERGY>(a, lane, c, d == 0, A < c, desc, xi[0], yi[0], zi[0], ax[0], ay[0], az[0], parked,
-                                             a.slab_j + blk * (3 * kTile), p12, p6);
-                        stored = true;
-                    }
-                }
                 if (!stored)
-                    n3_tile_pass<RT, W, ENERGY>(a, lane, c, d, l, mb, desc, xi, yi, zi, ax, ay, az, parked, jx, jy, jz, p12, p6);
+                    n3_tile_pass<RT, W, ENERGY>(a, lane, c, d, l, s0, ns, mb, desc, xi, yi, zi, ax, ay, az, parked, jx, jy, jz,
+                                                s_end, p12, p6);
                 s12 += p12;
                 s6 += p6;
             }
@@ -1125,7 +1078,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
             }
             if constexpr (W == 1) {
                 if (have && !stored) {
-                    double *o = a.slab_j + blk * (3 * kTile) + lane;
+                    double *o = a.slab_j + blk * (3 * kTile) + ((lane - s_end) & (kTile - 1));
                     o[0] = jx;
                     o[kTile] = jy;
                     o[2 * kTile] = jz;
@@ -1236,6 +1189,43 @@ __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float 
     }
 }
 
+// The same pair with the x and y components in ONE 64-bit register pair: v_pk_add_f32 forms both differences, v_pk_fma_f32
+// both row-side and both column-side force components (the force factor broadcast through op_sel), v_pk_add_f32 both energy
+// sums -- 16 VALU instructions per pair inside the cutoff instead of 21, five of them packed (a packed fp32 instruction
+// occupies the SIMD 1.5x as long as a plain one: profiles/r04_ubench_f32mix.txt).  Every component sees the operations and
+// roundings of pair_n3_f32: the results are bit-identical.  (What the compiler's own SLP packing did -- pairing
+// unrelated scalars and moving them together first -- lost 4.5 %: csrc/Makefile, -fno-slp-vectorize.)
+#ifndef LJMD_F32_PACK
+#define LJMD_F32_PACK 0
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int GEN, bool ENERGY>
+__device__ __forceinline__ void pair_n3_f32_packed(f32x2 xyi, float zi, f32x2 xyj, float zj, float Lf, float invLf,
+                                                   float rc2f, f32x2 &axy, float &az, f32x2 &jxy, float &jz,
+                                                   f32x2 &s6_12)
+{
+    f32x2 dxy = xyi - xyj;
+    float dz = zi - zj;
+    if constexpr (GEN & 1) dxy.x = fmaf(-Lf, __builtin_rintf(dxy.x * invLf), dxy.x);
+    if constexpr (GEN & 2) dxy.y = fmaf(-Lf, __builtin_rintf(dxy.y * invLf), dxy.y);
+    if constexpr (GEN & 4) dz = fmaf(-Lf, __builtin_rintf(dz * invLf), dz);
+    const float r2 = fmaf(dz, dz, fmaf(dxy.y, dxy.y, dxy.x * dxy.x));
+    if (r2 < rc2f) {
+        const float u = __builtin_amdgcn_rcpf(r2);
+        f32x2 e;
+        e.x = u * u * u;                                 // u^3
+        e.y = e.x * e.x;                                 // u^6
+        if constexpr (ENERGY) s6_12 += e;
+        const float g = fmaf(2.0f, e.y, -e.x) * u;
+        const f32x2 gg = {g, g};
+        axy = __builtin_elementwise_fma(gg, dxy, axy);
+        az = fmaf(g, dz, az);
+        jxy = __builtin_elementwise_fma(-gg, dxy, jxy);
+        jz = fmaf(-g, dz, jz);
+    }
+}
+
 template <int GEN, bool MASKED, bool ENERGY>
 __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], const float (&py)[kRowTiles],
                                                 const float (&pz)[kRowTiles], float (&fx)[kRowTiles],
@@ -1250,6 +1240,30 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
     // (+2 % / +-0 / +15 %), 4 or 6 waves per SIMD (+1 % / +2 %): profiles/r04_f32_far_kernel_forms.txt.  The loop runs at
     // the sum of its instructions' issue costs (tools/ubench_f32mix.hip): 29 % of its wave-level pair evaluations have all
     // 64 lanes outside the cutoff and skip 13 of their 22 instructions through the region's s_cbranch_execz.
+#if LJMD_F32_PACK
+    f32x2 pxy[kRowTiles], fxy[kRowTiles];
+#pragma unroll
+    for (int k = 0; k < kRowTiles; ++k) {
+        pxy[k] = f32x2{px[k], py[k]};
+        fxy[k] = f32x2{fx[k], fy[k]};
+    }
+    f32x2 xyj = {xj, yj}, jxy = {jx, jy}, s6_12 = {s6, s12};
+    for (int s = 0; s < kTile; ++s) {
+#pragma unroll
+        for (int k = 0; k < kRowTiles; ++k)
+            if (!MASKED || ((mb >> k) & 1u))
+                pair_n3_f32_packed<GEN, ENERGY>(pxy[k], pz[k], xyj, zj, Lf, invLf, rc2f, fxy[k], fz[k], jxy, jz, s6_12);
+        xyj.x = dpp_rotate_f32(xyj.x); xyj.y = dpp_rotate_f32(xyj.y); zj = dpp_rotate_f32(zj);
+        jxy.x = dpp_rotate_f32(jxy.x); jxy.y = dpp_rotate_f32(jxy.y); jz = dpp_rotate_f32(jz);
+    }
+#pragma unroll
+    for (int k = 0; k < kRowTiles; ++k) {
+        fx[k] = fxy[k].x;
+        fy[k] = fxy[k].y;
+    }
+    jx = jxy.x; jy = jxy.y;
+    s6 = s6_12.x; s12 = s6_12.y;
+#else
     for (int s = 0; s < kTile; ++s) {
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k)
@@ -1259,6 +1273,7 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
         xj = dpp_rotate_f32(xj); yj = dpp_rotate_f32(yj); zj = dpp_rotate_f32(zj);
         jx = dpp_rotate_f32(jx); jy = dpp_rotate_f32(jy); jz = dpp_rotate_f32(jz);
     }
+#endif
 }
 
 // 5 waves per SIMD (96 VGPRs; 20 spilled, none of them in the rotation loop): 11.73 -> 11.59 ms at n = 262144; 6: +-0, 8: +8 %
@@ -2025,31 +2040,39 @@ __global__ __launch_bounds__(kBlock) void kick_finalize_kernel(IntegrateArgs a, 
 // launch leaves its record to the NEXT launch, whose extra block (index = number of tiles) folds it (`prev`) while the
 // tiles are being reduced -- no device-wide fence, no ticket, no last block.  The last launch of a batch draws tickets as
 // before and its last block folds the pending record, then its own.  Records are appended in step order either way.
-template <bool N3, bool KICK, bool DRIFT>
-__global__ __launch_bounds__(kBlock) void tile_tail_kernel(ReduceArgs ra, IntegrateArgs a, FinalizeArgs f, FinalizeArgs prev)
+// TPB = tiles per block = tiles per Newton-3 row group (1, or 2: pair_n3_kernel<., 2, .> for small systems): the block's
+// 4 TPB waves reduce TPB consecutive tiles side by side (wave 4 b + q = tile b's terms q, q + 4, ...: the split and the
+// order of the one-tile form), then wave 0 integrates them one after the other -- the tiles of a row group share the
+// frame of their coherent copy (its first particle: tile_boxes_kernel), so the second tile needs the first one's result.
+template <bool N3, bool KICK, bool DRIFT, int TPB>
+__global__ __launch_bounds__(kBlock * TPB) void tile_tail_kernel(ReduceArgs ra, IntegrateArgs a, FinalizeArgs f, FinalizeArgs prev)
 {
-    __shared__ double part[kWavesPerBlock][3][kTile];
+    __shared__ double part[kWavesPerBlock * TPB][3][kTile];
     __shared__ double red[5 * kWavesPerBlock];
     __shared__ bool last;
-    if ((int)blockIdx.x == a.P / kTile) {                       // the extra block: the previous step's record
+    if ((int)blockIdx.x == a.P / (kTile * TPB)) {               // the extra block: the previous step's record
+        if (threadIdx.x >= kBlock) return;                      // (finalize_body is written for 256 threads)
         if (prev.ring) finalize_body(prev, red);
         return;
     }
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = wave & (kWavesPerBlock - 1), tb = wave / kWavesPerBlock;
+    const int tile = blockIdx.x * TPB + tb;
     const int i = tile * kTile + lane;                          // slot
-    // wave 0 integrates the tile behind the reduction: its loads go out first and arrive while the partial sums are formed
-    double v_in[3] = {0.0, 0.0, 0.0}, r_in[3] = {0.0, 0.0, 0.0}, ru_in[3] = {0.0, 0.0, 0.0};
-    if (q == 0) {
+    // wave 0 integrates the tiles behind the reduction: its loads go out first and arrive while the partial sums are formed
+    double v_in[TPB][3], r_in[TPB][3], ru_in[TPB][3];
+    if (wave == 0) {
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            const size_t o = (size_t)ax * a.P + i;
-            if constexpr (KICK || DRIFT) v_in[ax] = a.v[o];
-            if constexpr (DRIFT) {
-                r_in[ax] = a.r[o];
-                ru_in[ax] = a.ru[o];
+        for (int b = 0; b < TPB; ++b)
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                const size_t o = (size_t)ax * a.P + i + b * kTile;
+                v_in[b][ax] = r_in[b][ax] = ru_in[b][ax] = 0.0;
+                if constexpr (KICK || DRIFT) v_in[b][ax] = a.v[o];
+                if constexpr (DRIFT) {
+                    r_in[b][ax] = a.r[o];
+                    ru_in[b][ax] = a.ru[o];
+                }
             }
-        }
     }
     double s[3] = {0.0, 0.0, 0.0};
     // The order of reduce_forces_kernel (single rank): the row-side slices, then the column-side blocks, wave q taking
@@ -2076,62 +2099,68 @@ __global__ __launch_bounds__(kBlock) void tile_tail_kernel(ReduceArgs ra, Integr
             s[2] += on ? b2 : 0.0;
         }
     }
-    part[q][0][lane] = s[0];
-    part[q][1][lane] = s[1];
-    part[q][2][lane] = s[2];
+    part[wave][0][lane] = s[0];
+    part[wave][1][lane] = s[1];
+    part[wave][2][lane] = s[2];
     __syncthreads();
-    if (q == 0) {
-        double k2[3] = {0.0, 0.0, 0.0}, rn[3] = {0.0, 0.0, 0.0};
+    if (wave == 0) {
+        double anchor[3] = {0.0, 0.0, 0.0};                     // the row group's frame: its first tile's first particle
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            double t = part[0][ax][lane];
+        for (int b = 0; b < TPB; ++b) {
+            double k2[3] = {0.0, 0.0, 0.0}, rn[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-            for (int w = 1; w < kWavesPerBlock; ++w) t += part[w][ax][lane];
-            const size_t o = (size_t)ax * a.P + i;
-            const double acc = 24.0 * t;                        // kick_kernel
-            a.a[o] = acc;
-            double vel = v_in[ax];
+            for (int ax = 0; ax < 3; ++ax) {
+                double t = part[kWavesPerBlock * b][ax][lane];
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) t += part[kWavesPerBlock * b + w][ax][lane];
+                const size_t o = (size_t)ax * a.P + i + b * kTile;
+                const double acc = 24.0 * t;                        // kick_kernel
+                a.a[o] = acc;
+                double vel = v_in[b][ax];
+                if constexpr (KICK) {
+                    vel = vel + acc * a.dt_half;
+                    k2[ax] = vel * vel;
+                }
+                if constexpr (DRIFT) {                              // drift_kick_kernel<0> of the next step
+                    const double r0 = r_in[b][ax];
+                    double r1 = (r0 + vel * a.dt) + acc * a.dt_sq_half;
+                    r1 = r1 - a.L * __builtin_floor(r1 * a.invL);
+                    double d = r1 - r0;
+                    d = d - a.L * __builtin_round(d * a.invL);
+                    a.r[o] = r1;
+                    a.ru[o] = ru_in[b][ax] + d;
+                    rn[ax] = r1;
+                    vel = vel + acc * a.dt_half;
+                }
+                if constexpr (KICK || DRIFT) a.v[o] = vel;
+            }
             if constexpr (KICK) {
-                vel = vel + acc * a.dt_half;
-                k2[ax] = vel * vel;
-            }
-            if constexpr (DRIFT) {                              // drift_kick_kernel<0> of the next step
-                const double r0 = r_in[ax];
-                double r1 = (r0 + vel * a.dt) + acc * a.dt_sq_half;
-                r1 = r1 - a.L * __builtin_floor(r1 * a.invL);
-                double d = r1 - r0;
-                d = d - a.L * __builtin_round(d * a.invL);
-                a.r[o] = r1;
-                a.ru[o] = ru_in[ax] + d;
-                rn[ax] = r1;
-                vel = vel + acc * a.dt_half;
-            }
-            if constexpr (KICK || DRIFT) a.v[o] = vel;
-        }
-        if constexpr (KICK) {
-            const double kx = wave_sum(k2[0]), ky = wave_sum(k2[1]), kz = wave_sum(k2[2]);
-            if (lane == 0) {
-                double *w = const_cast<double *>(f.ke_tile) + 3 * (size_t)tile;
-                w[0] = kx; w[1] = ky; w[2] = kz;
-            }
-        }
-        if constexpr (DRIFT) {
-            if (a.pos_tc) {                                     // tile frame: one tile per row group here (RT = 1)
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    rn[ax] = tile_frame(rn[ax], wave_first(rn[ax]), a.L, a.invL);
-                    a.pos_tc[(size_t)ax * a.P + i] = rn[ax];
+                const double kx = wave_sum(k2[0]), ky = wave_sum(k2[1]), kz = wave_sum(k2[2]);
+                if (lane == 0) {
+                    double *w = const_cast<double *>(f.ke_tile) + 3 * (size_t)(tile + b);
+                    w[0] = kx; w[1] = ky; w[2] = kz;
                 }
             }
-            const double lx = wave_min(rn[0]), ly = wave_min(rn[1]), lz = wave_min(rn[2]);
-            const double hx = wave_max(rn[0]), hy = wave_max(rn[1]), hz = wave_max(rn[2]);
-            if (lane == 0) {
-                double *o = a.bbox + (size_t)tile * kBoxStride;
-                o[0] = lx; o[1] = ly; o[2] = lz;
-                o[3] = hx; o[4] = hy; o[5] = hz;
+            if constexpr (DRIFT) {
+                if (a.pos_tc) {                                     // tile frame: the block is the row group
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        if (b == 0) anchor[ax] = wave_first(rn[ax]);
+                        rn[ax] = tile_frame(rn[ax], anchor[ax], a.L, a.invL);
+                        a.pos_tc[(size_t)ax * a.P + i + b * kTile] = rn[ax];
+                    }
+                }
+                const double lx = wave_min(rn[0]), ly = wave_min(rn[1]), lz = wave_min(rn[2]);
+                const double hx = wave_max(rn[0]), hy = wave_max(rn[1]), hz = wave_max(rn[2]);
+                if (lane == 0) {
+                    double *o = a.bbox + (size_t)(tile + b) * kBoxStride;
+                    o[0] = lx; o[1] = ly; o[2] = lz;
+                    o[3] = hx; o[4] = hy; o[5] = hz;
+                }
             }
         }
     }
+    if (threadIdx.x >= kBlock) return;                     // (the record is folded by 256 threads: finalize_body)
     if (!a.ticket) return;                                 // this step's record: the next launch's extra block
     if (threadIdx.x == 0) {
         __threadfence();                                   // this block's partial is visible device-wide ...
@@ -2388,17 +2417,23 @@ hipError_t launch_tile_tail(const ReduceArgs &ra, const IntegrateArgs &a, const 
 {
     // a.ticket == NULL: the record of this launch is folded by the next one; prev.ring != NULL: a record is pending --
     // it gets an extra block here, or (with tickets) the last block takes it first
-    const dim3 grid(a.P / kTile + ((!a.ticket && prev.ring) ? 1 : 0)), block(kBlock);
+    // one block per Newton-3 row group of 1 or 2 tiles (the gather kernel's tiles stand alone)
     const bool n3 = ra.slab_j != nullptr;
-#define LJMD_TAIL(N3_, KICK_, DRIFT_) hipLaunchKernelGGL((tile_tail_kernel<N3_, KICK_, DRIFT_>), grid, block, 0, s, ra, a, f, prev)
-    if (n3) {
-        if (kick && drift) LJMD_TAIL(true, true, true);
-        else if (kick) LJMD_TAIL(true, true, false);
-        else LJMD_TAIL(true, false, false);
+    const int tpb = (n3 && ra.RT == 2) ? 2 : 1;
+    const dim3 grid(a.P / (kTile * tpb) + ((!a.ticket && prev.ring) ? 1 : 0)), block(kBlock * tpb);
+#define LJMD_TAIL(N3_, KICK_, DRIFT_, TPB_) hipLaunchKernelGGL((tile_tail_kernel<N3_, KICK_, DRIFT_, TPB_>), grid, block, 0, s, ra, a, f, prev)
+    if (n3 && tpb == 2) {
+        if (kick && drift) LJMD_TAIL(true, true, true, 2);
+        else if (kick) LJMD_TAIL(true, true, false, 2);
+        else LJMD_TAIL(true, false, false, 2);
+    } else if (n3) {
+        if (kick && drift) LJMD_TAIL(true, true, true, 1);
+        else if (kick) LJMD_TAIL(true, true, false, 1);
+        else LJMD_TAIL(true, false, false, 1);
     } else {
-        if (kick && drift) LJMD_TAIL(false, true, true);
-        else if (kick) LJMD_TAIL(false, true, false);
-        else LJMD_TAIL(false, false, false);
+        if (kick && drift) LJMD_TAIL(false, true, true, 1);
+        else if (kick) LJMD_TAIL(false, true, false, 1);
+        else LJMD_TAIL(false, false, false, 1);
     }
 #undef LJMD_TAIL
     return hipGetLastError();
