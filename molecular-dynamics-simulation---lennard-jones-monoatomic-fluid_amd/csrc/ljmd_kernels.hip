@@ -1189,43 +1189,6 @@ __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float 
     }
 }
 
-// The same pair with the x and y components in ONE 64-bit register pair: v_pk_add_f32 forms both differences, v_pk_fma_f32
-// both row-side and both column-side force components (the force factor broadcast through op_sel), v_pk_add_f32 both energy
-// sums -- 16 VALU instructions per pair inside the cutoff instead of 21, five of them packed (a packed fp32 instruction
-// occupies the SIMD 1.5x as long as a plain one: profiles/r04_ubench_f32mix.txt).  Every component sees the operations and
-// roundings of pair_n3_f32: the results are bit-identical.  (What the compiler's own SLP packing did -- pairing
-// unrelated scalars and moving them together first -- lost 4.5 %: csrc/Makefile, -fno-slp-vectorize.)
-#ifndef LJMD_F32_PACK
-#define LJMD_F32_PACK 0
-#endif
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int GEN, bool ENERGY>
-__device__ __forceinline__ void pair_n3_f32_packed(f32x2 xyi, float zi, f32x2 xyj, float zj, float Lf, float invLf,
-                                                   float rc2f, f32x2 &axy, float &az, f32x2 &jxy, float &jz,
-                                                   f32x2 &s6_12)
-{
-    f32x2 dxy = xyi - xyj;
-    float dz = zi - zj;
-    if constexpr (GEN & 1) dxy.x = fmaf(-Lf, __builtin_rintf(dxy.x * invLf), dxy.x);
-    if constexpr (GEN & 2) dxy.y = fmaf(-Lf, __builtin_rintf(dxy.y * invLf), dxy.y);
-    if constexpr (GEN & 4) dz = fmaf(-Lf, __builtin_rintf(dz * invLf), dz);
-    const float r2 = fmaf(dz, dz, fmaf(dxy.y, dxy.y, dxy.x * dxy.x));
-    if (r2 < rc2f) {
-        const float u = __builtin_amdgcn_rcpf(r2);
-        f32x2 e;
-        e.x = u * u * u;                                 // u^3
-        e.y = e.x * e.x;                                 // u^6
-        if constexpr (ENERGY) s6_12 += e;
-        const float g = fmaf(2.0f, e.y, -e.x) * u;
-        const f32x2 gg = {g, g};
-        axy = __builtin_elementwise_fma(gg, dxy, axy);
-        az = fmaf(g, dz, az);
-        jxy = __builtin_elementwise_fma(-gg, dxy, jxy);
-        jz = fmaf(-g, dz, jz);
-    }
-}
-
 template <int GEN, bool MASKED, bool ENERGY>
 __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], const float (&py)[kRowTiles],
                                                 const float (&pz)[kRowTiles], float (&fx)[kRowTiles],
@@ -1237,33 +1200,10 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
     // The per-pair `if (r2 < rc2f)` stays an exec-mask region and the loop stays rolled: measured against branch-free
     // forms (u = med3(1/r^2, 0, (rc^2 - r^2) 2^60) or a select: +13 ... +30 %), one wave-uniform branch per pair or per
     // step (+9 % / +40 %), the column offsets parked in LDS instead of rotating (+-0), 2 / 8 / 64 unrolled steps
-    // (+2 % / +-0 / +15 %), 4 or 6 waves per SIMD (+1 % / +2 %): profiles/r04_f32_far_kernel_forms.txt.  The loop runs at
+    // (+2 % / +-0 / +15 %), 4 or 6 waves per SIMD (+1 % / +2 %), x and y packed into v_pk_add / v_pk_fma_f32 by hand (+4 %
+    // for a single packed instruction): profiles/r04_f32_far_kernel_forms.txt.  The loop runs at
     // the sum of its instructions' issue costs (tools/ubench_f32mix.hip): 29 % of its wave-level pair evaluations have all
     // 64 lanes outside the cutoff and skip 13 of their 22 instructions through the region's s_cbranch_execz.
-#if LJMD_F32_PACK
-    f32x2 pxy[kRowTiles], fxy[kRowTiles];
-#pragma unroll
-    for (int k = 0; k < kRowTiles; ++k) {
-        pxy[k] = f32x2{px[k], py[k]};
-        fxy[k] = f32x2{fx[k], fy[k]};
-    }
-    f32x2 xyj = {xj, yj}, jxy = {jx, jy}, s6_12 = {s6, s12};
-    for (int s = 0; s < kTile; ++s) {
-#pragma unroll
-        for (int k = 0; k < kRowTiles; ++k)
-            if (!MASKED || ((mb >> k) & 1u))
-                pair_n3_f32_packed<GEN, ENERGY>(pxy[k], pz[k], xyj, zj, Lf, invLf, rc2f, fxy[k], fz[k], jxy, jz, s6_12);
-        xyj.x = dpp_rotate_f32(xyj.x); xyj.y = dpp_rotate_f32(xyj.y); zj = dpp_rotate_f32(zj);
-        jxy.x = dpp_rotate_f32(jxy.x); jxy.y = dpp_rotate_f32(jxy.y); jz = dpp_rotate_f32(jz);
-    }
-#pragma unroll
-    for (int k = 0; k < kRowTiles; ++k) {
-        fx[k] = fxy[k].x;
-        fy[k] = fxy[k].y;
-    }
-    jx = jxy.x; jy = jxy.y;
-    s6 = s6_12.x; s12 = s6_12.y;
-#else
     for (int s = 0; s < kTile; ++s) {
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k)
@@ -1273,7 +1213,6 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
         xj = dpp_rotate_f32(xj); yj = dpp_rotate_f32(yj); zj = dpp_rotate_f32(zj);
         jx = dpp_rotate_f32(jx); jy = dpp_rotate_f32(jy); jz = dpp_rotate_f32(jz);
     }
-#endif
 }
 
 // 5 waves per SIMD (96 VGPRs; 20 spilled, none of them in the rotation loop): 11.73 -> 11.59 ms at n = 262144; 6: +-0, 8: +8 %
