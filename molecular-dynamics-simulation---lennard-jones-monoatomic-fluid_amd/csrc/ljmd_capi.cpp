@@ -73,6 +73,9 @@ GeometryArgs geometry_args(ljmd_t *h)
     a.rc2_skin = h->rc2 * (1.0 + 1e-10);
     a.mask_far = h->d_mask_far;       // NULL unless mixed precision
     a.rsplit2 = h->r_split * h->r_split;
+    // 2^(26/3) = 406.3747: r^-6 < 2^-26 beyond it, 406.5 with a margin of 1e-3 for the fp32 roundings of u^3 (pair_n3_f32<., VFAR>);
+    // LJMD_FP32_VFAR=0 switches the form off
+    a.rvfar2 = env_int("LJMD_FP32_VFAR", 1) != 0 ? 406.5 : HUGE_VAL;
     a.pertile_images = env_int("LJMD_N3_PERTILE", 1) != 0 ? 1 : 0;
     a.both_ties = h->both_ties ? 1 : 0;
     return a;
@@ -146,7 +149,7 @@ ReduceArgs reduce_args(ljmd_t *h, int nslab, bool n3)
     a.slab = h->d_slab;
     a.slab_j = n3 ? h->d_slab_j : nullptr;
     a.flag_j = n3 ? h->d_flag_j : nullptr;
-    a.slab_j2 = (n3 && h->mode == LJMD_PRECISION_FP32_FORCE) ? h->d_slab_j2 : nullptr;
+    a.slab_j2 = (n3 && h->mode == LJMD_PRECISION_FP32_FORCE) ? reinterpret_cast<const float *>(h->d_slab_j2) : nullptr;
     a.flag_j2 = (n3 && h->mode == LJMD_PRECISION_FP32_FORCE) ? h->d_flag_j2 : nullptr;
     a.fpart = h->d_fpart;
     a.nslab = nslab;
@@ -1041,7 +1044,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
             LJMD_HIP(h, hipMalloc(&h->d_mask_far, (size_t)h->TB * h->W * sizeof(uint64_t)));
             LJMD_HIP(h, hipMalloc(&h->d_desc_far, (size_t)h->NGo * h->T * sizeof(unsigned)));
             const size_t n_blk2 = (size_t)h->T * h->CS2;
-            LJMD_HIP(h, hipMalloc(&h->d_slab_j2, n_blk2 * 3 * kTile * sizeof(double)));
+            LJMD_HIP(h, hipMalloc(&h->d_slab_j2, n_blk2 * 3 * kTile * sizeof(float)));     // fp32 blocks (pair_n3_f32_kernel)
             LJMD_HIP(h, hipMalloc(&h->d_flag_j2, n_blk2));
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j2, 0, n_blk2, h->stream));
         }

@@ -108,7 +108,7 @@ struct ReduceArgs {
     const double *slab;     // row side [nslab][3][P]
     const double *slab_j;   // column side (Newton-3) or NULL
     const unsigned char *flag_j;
-    const double *slab_j2;  // second column-side set (fp32 far pass of the mixed-precision mode: [T][CS2] blocks) or NULL
+    const float *slab_j2;   // second column-side set (fp32 far pass of the mixed-precision mode: [T][CS2] blocks of floats) or NULL
     const unsigned char *flag_j2;
     double *fpart;
     int nslab, P, G, rank, TB;
@@ -139,6 +139,8 @@ struct GeometryArgs {
     int RT;                 // tiles per Newton-3 row group (same-group pairs always count as NEAR)
     double L, invL, rc2_skin;   // rc^2 * (1 + 1e-10): skip only when provably outside
     double rsplit2;         // r_split^2
+    double rvfar2;          // mixed precision: box distance^2 beyond which a far pass is VERY FAR (u^3 = r^-6 < 2^-26: the u^6
+                            // terms lie below the fp32 resolution of the u^3 terms; pair_n3_f32<., VFAR>), or +inf: never
     int pertile_images;     // tile_class: row tiles may take their own periodic image on a single general axis (LJMD_N3_PERTILE)
     int both_ties;          // tile_class: the tie d = NG / 2 is visited from both sides (N3Args::both_ties)
 };

@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
                     GeometryArgs ga;
                     ga.pos = nullptr; ga.bbox = const_cast<double *>(a.bbox); ga.pos_tc = nullptr; ga.mask = nullptr; ga.mask_far = nullptr;
                     ga.P = a.P; ga.G = a.G; ga.rank = a.rank; ga.TB = a.TB; ga.T = a.T; ga.W = a.W; ga.RT = RT;
-                    ga.L = a.L; ga.invL = a.invL; ga.rc2_skin = a.rc2_skin; ga.rsplit2 = 0.0; ga.pertile_images = 0;
+                    ga.L = a.L; ga.invL = a.invL; ga.rc2_skin = a.rc2_skin; ga.rsplit2 = 0.0; ga.rvfar2 = 0.0; ga.pertile_images = 0;
                     ga.both_ties = a.both_ties;
                     unsigned dsc = 0;
                     (void)tile_class<RT>(ga, a.invL, a.rc2, a.S, Al, c, dsc, nullptr, nullptr);
@@ -1160,7 +1160,13 @@ __device__ __forceinline__ float dpp_rotate_f32(float v)
 
 // GEN: bit k set = axis k needs the general minimum image; clear = its common image shift is already folded
 // into the row offsets (0 = the former UNIFORM, 7 = all general)
-template <int GEN, bool ENERGY>
+// VFAR: every pair of the pass has r^2 > 2^(26/3) (r > 20.16 sigma), i.e. u^3 = r^-6 < 2^-26.  Then 2 u^6 < ulp(u^3) / 2 and
+// fmaf(2, u^6, -u^3) IS -u^3, bit for bit: the loop leaves u^6 out -- three of the fourteen instructions behind the cutoff
+// test -- and the accelerations keep their bits.  What changes is the energy sum S12 = sum u^6, which loses the terms
+// beyond 20.16 sigma: n 4 pi rho / (9 r^9) = 2e-12 n, 3e-13 of epot (the mixed mode's own fp32 noise is 7e-11).
+// (An INNER form -- no cutoff test where the boxes prove every pair inside -- was built twice and is 3.4 / 4.6 % SLOWER although
+// it issues one VALU and three SALU instructions less per pair: profiles/r03_cluster_passes.txt, r04_f32_far_kernel_forms.txt.)
+template <int GEN, bool ENERGY, bool VFAR = false>
 __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float xj, float yj, float zj,
                                             float Lf, float invLf, float rc2f,
                                             float &ax, float &ay, float &az, float &jx, float &jy, float &jz,
@@ -1174,12 +1180,19 @@ __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float 
     if (r2 < rc2f) {
         const float u = __builtin_amdgcn_rcpf(r2);
         const float u3 = u * u * u;
-        const float u6 = u3 * u3;
-        if constexpr (ENERGY) {
-            s12 += u6;
-            s6 += u3;
+        float g;
+        if constexpr (VFAR) {
+            // (GEN == 0: the caller takes sum u^3 of the pass from its force sums -- below, in pair_n3_f32_kernel -- and nothing is added here)
+            if constexpr (ENERGY && GEN != 0) s6 += u3;
+            g = -u3 * u;                                  // = fmaf(2, u^6, -u^3) * u, exactly
+        } else {
+            const float u6 = u3 * u3;
+            if constexpr (ENERGY) {
+                s12 += u6;
+                s6 += u3;
+            }
+            g = fmaf(2.0f, u6, -u3) * u;
         }
-        const float g = fmaf(2.0f, u6, -u3) * u;
         ax = fmaf(g, dx, ax);
         ay = fmaf(g, dy, ay);
         az = fmaf(g, dz, az);
@@ -1189,7 +1202,7 @@ __device__ __forceinline__ void pair_n3_f32(float xi, float yi, float zi, float 
     }
 }
 
-template <int GEN, bool MASKED, bool ENERGY>
+template <int GEN, bool MASKED, bool ENERGY, bool VFAR>
 __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], const float (&py)[kRowTiles],
                                                 const float (&pz)[kRowTiles], float (&fx)[kRowTiles],
                                                 float (&fy)[kRowTiles], float (&fz)[kRowTiles],
@@ -1208,7 +1221,7 @@ __device__ __forceinline__ void column_loop_f32(const float (&px)[kRowTiles], co
 #pragma unroll
         for (int k = 0; k < kRowTiles; ++k)
             if (!MASKED || ((mb >> k) & 1u))
-                pair_n3_f32<GEN, ENERGY>(px[k], py[k], pz[k], xj, yj, zj, Lf, invLf, rc2f, fx[k], fy[k], fz[k],
+                pair_n3_f32<GEN, ENERGY, VFAR>(px[k], py[k], pz[k], xj, yj, zj, Lf, invLf, rc2f, fx[k], fy[k], fz[k],
                                      jx, jy, jz, s12, s6);
         xj = dpp_rotate_f32(xj); yj = dpp_rotate_f32(yj); zj = dpp_rotate_f32(zj);
         jx = dpp_rotate_f32(jx); jy = dpp_rotate_f32(jy); jz = dpp_rotate_f32(jz);
@@ -1294,14 +1307,33 @@ __global__ __launch_bounds__(kTile, 5) void pair_n3_f32_kernel(N3Args a)
                 fx[k] = fy[k] = fz[k] = 0.0f;
             }
             float jx = 0.0f, jy = 0.0f, jz = 0.0f, t12 = 0.0f, t6 = 0.0f;
-#define LJMD_LOOP32(GEN_, MASKED_)                                                                              \
-    column_loop_f32<GEN_, MASKED_, ENERGY>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6)
+#define LJMD_LOOP32(GEN_, MASKED_, VFAR_)                                                                       \
+    column_loop_f32<GEN_, MASKED_, ENERGY, VFAR_>(px, py, pz, fx, fy, fz, xj, yj, zj, mb, Lf, invLf, rc2f, jx, jy, jz, t12, t6)
+#define LJMD_LOOP32_GEN(GEN_)                                                                                   \
+    do {                                                                                                        \
+        if (vfar) { if (all4) LJMD_LOOP32(GEN_, false, true); else LJMD_LOOP32(GEN_, true, true); }             \
+        else      { if (all4) LJMD_LOOP32(GEN_, false, false); else LJMD_LOOP32(GEN_, true, false); }           \
+    } while (0)
             const bool all4 = mb == kAllRows;
-            if (gen == 0)      { if (all4) LJMD_LOOP32(0, false); else LJMD_LOOP32(0, true); }
-            else if (gen == 1) { if (all4) LJMD_LOOP32(1, false); else LJMD_LOOP32(1, true); }
-            else if (gen == 2) { if (all4) LJMD_LOOP32(2, false); else LJMD_LOOP32(2, true); }
-            else if (gen == 4) { if (all4) LJMD_LOOP32(4, false); else LJMD_LOOP32(4, true); }
-            else               { if (all4) LJMD_LOOP32(7, false); else LJMD_LOOP32(7, true); }
+            const bool vfar = ((desc >> 28) & 1u) != 0;       // every pair beyond 20.16 sigma (tile_class)
+            if (gen == 0)      LJMD_LOOP32_GEN(0);
+            else if (gen == 1) LJMD_LOOP32_GEN(1);
+            else if (gen == 2) LJMD_LOOP32_GEN(2);
+            else if (gen == 4) LJMD_LOOP32_GEN(4);
+            else               LJMD_LOOP32_GEN(7);
+#undef LJMD_LOOP32_GEN
+            if (ENERGY && vfar && gen == 0) {
+                // sum u^3 of a VERY FAR pass without a general axis, from its force sums: there g = -u^4 and the displacement
+                // is the plain difference d = p_i - q_j of the offsets the loop ran on, so
+                //   sum u^3 = -sum g d.d = -( sum_i p_i . f_i + sum_j q_j . j_j ),   f_i = sum_j g d,  j_j = -sum_i g d
+                // -- 15 FMAs per pass in place of one addition per pair (256 per lane).  q (offsets from the column tile's
+                // own centre) is small and p ~ d: no cancellation; fp32 like the sum it replaces.  (After 64 rotations the
+                // column particle and its sums are back in their home lane.)
+                float w = fmaf(zj, jz, fmaf(yj, jy, xj * jx));
+#pragma unroll
+                for (int k = 0; k < kRowTiles; ++k) w = fmaf(pz[k], fz[k], fmaf(py[k], fy[k], fmaf(px[k], fx[k], w)));
+                t6 = -w;
+            }
 #undef LJMD_LOOP32
 #pragma unroll
             for (int k = 0; k < kRowTiles; ++k) {
@@ -1311,10 +1343,12 @@ __global__ __launch_bounds__(kTile, 5) void pair_n3_f32_kernel(N3Args a)
             }
             s12 += (double)t12;
             s6 += (double)t6;
-            double *o = a.slab_j + blk * (3 * kTile) + lane;
-            o[0] = (double)jx;
-            o[kTile] = (double)jy;
-            o[2 * kTile] = (double)jz;
+            // the column-side sums of a far pass ARE fp32: their blocks are stored as such (half the slab traffic of this
+            // kernel and of the reduction, which widens them exactly before it adds)
+            float *o = reinterpret_cast<float *>(a.slab_j) + blk * (3 * kTile) + lane;
+            o[0] = jx;
+            o[kTile] = jy;
+            o[2 * kTile] = jz;
             if (lane == 0) a.flag_j[blk] = 1;
         }
     }
@@ -1454,6 +1488,7 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
     double ghi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
     const double *cbx = a.bbox + (size_t)c * kBoxStride;
     unsigned mb = 0, mb_far = 0;
+    bool vfar = true;
     for (int k = 0; k < RT; ++k) {
         const int tl = RT * Al + k, I = a.rank * a.TB + tl;
         const double *bb = a.bbox + (size_t)I * kBoxStride;
@@ -1474,6 +1509,7 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
         if (desc_far) {
             const bool near = (d2 <= a.rsplit2) || (c / RT == I / RT);
             mb_far |= (unsigned)(keep && !near) << k;
+            if (keep && !near && !(d2 > a.rvfar2)) vfar = false;   // a far row tile closer than the VERY FAR radius
             keep = keep && near;
         }
         mb |= (unsigned)keep << k;
@@ -1633,7 +1669,9 @@ __device__ __forceinline__ bool tile_class(const GeometryArgs &a, double invL, d
         }
     }
     desc_out = mb | cls;
-    if (desc_far) desc_far[(size_t)Al * a.T + c] = mb_far | cls;
+    // far pass: bit 28 (free here: no per-tile images in the mixed mode) = VERY FAR
+    // (FULL passes only: the kernel multiplies offsets with force sums, and a padding slot's offset is NaN)
+    if (desc_far) desc_far[(size_t)Al * a.T + c] = mb_far | cls | ((unsigned)(vfar && full && mb_far != 0) << 28);
     return true;
 }
 
@@ -1742,7 +1780,7 @@ __global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
         // at a time: a stream of independent loads, nothing is read for a block nobody wrote.
         const int c = g * a.TB + blockIdx.x;                    // global column tile (= this workgroup's tile)
         const int qs = __builtin_amdgcn_readfirstlane(q);
-        auto add_blocks = [&](const double *slab, const unsigned char *flags, int CS) {
+        auto add_blocks = [&](const auto *slab, const unsigned char *flags, int CS) {
             constexpr int U = 4;
             const size_t base = (size_t)c * CS;
             unsigned f = lane < CS ? flags[base + lane] : 0u;
@@ -1758,10 +1796,10 @@ __global__ __launch_bounds__(kBlock) void reduce_forces_kernel(ReduceArgs a)
                         if (m) {
                             const int j = j0 + __builtin_ctzll(m);
                             m &= m - 1;
-                            const double *b = slab + (base + j) * (3 * kTile) + lane;
-                            v[u][0] = b[0];
-                            v[u][1] = b[kTile];
-                            v[u][2] = b[2 * kTile];
+                            const auto *b = slab + (base + j) * (3 * kTile) + lane;
+                            v[u][0] = (double)b[0];
+                            v[u][1] = (double)b[kTile];
+                            v[u][2] = (double)b[2 * kTile];
                         }
                     }
 #pragma unroll

@@ -580,6 +580,28 @@ def test_mixed_precision_full_parity_vs_oracle_n262144(oracle_rows_n262144, spli
     assert np.abs(a - ao).max() <= tol_a * amax, np.abs(a - ao).max() / amax
 
 
+def test_mixed_precision_very_far_passes_keep_the_force_bits(monkeypatch):
+    """The cheaper form of the fp32 far loop (pair_n3_f32<., VFAR>) at the bench size: passes whose boxes are farther apart
+    than 20.16 sigma (r^-6 < 2^-26) leave u^6 out -- in fp32 2 u^6 - u^3 IS -u^3 there.  Every bit of the accelerations
+    stays; the energy sums lose sum u^6 beyond 20.16 sigma (3e-13 of epot, measured 8e-14 / 2.5e-12 / 1.6e-13 on the three
+    scalars)."""
+    from ljmd_amd import _lib
+    n = 262144
+    p, r, v = synthetic.make_config(n, seed=5)
+    out = {}
+    for key in ("0", "1"):
+        monkeypatch.setenv("LJMD_FP32_VFAR", key)
+        with Engine(p, precision_mode=_lib.PRECISION_FP32_FORCE) as eng:
+            eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+            sc = np.array(eng.compute_forces())
+            a = np.stack(eng.get_state(("a",))["a"])
+        out[key] = (sc, a)
+    assert np.array_equal(out["1"][1], out["0"][1])
+    dev = np.abs(out["1"][0] - out["0"][0]) / np.abs(out["0"][0])
+    print("very far passes: relative change of epot, d_epot, dd_epot", dev)
+    assert 0.0 < dev.max() <= 1e-11
+
+
 def test_mixed_precision_energy_series_vs_oracle_n16384(oracle):
     """Mixed-precision trajectory against the ORACLE's own velocity-Verlet series (sequential reference arithmetic),
     n = 16384 (the smallest size the mode accepts), 30 steps from the jittered lattice (~40 s of one host core):
