@@ -210,16 +210,19 @@ def test_thin_fortran_driver_sampled_segments_write_the_same_bytes(tmp_path, gpu
     subprocess.run([str(PKG / "bin" / "md_initial_config_gpu")], cwd=tmp_path, check=True, timeout=300)
     files = ("instantaneous_energies.dat", "rva.dat", "md_final_results.txt")
     got = {}
-    for sampled in ("1", "0"):
+    # (third run: LJMD_ASYNC_IO=0 -- every sample written before the next steps are enqueued instead of beside them)
+    for sampled, async_io in (("1", "1"), ("0", "1"), ("1", "0")):
         for f in files:
             (tmp_path / "outputs" / "one_run" / f).unlink(missing_ok=True)
-        env = dict(os.environ, LJMD_SAMPLED_STEPS=sampled, LJMD_GPUS=gpus, LJMD_DEVICES=",".join(["0"] * int(gpus)))
+        env = dict(os.environ, LJMD_SAMPLED_STEPS=sampled, LJMD_ASYNC_IO=async_io, LJMD_GPUS=gpus,
+                   LJMD_DEVICES=",".join(["0"] * int(gpus)))
         out = subprocess.run([str(PKG / "bin" / "md_simulation_gpu")], cwd=tmp_path, check=True, capture_output=True,
                              text=True, timeout=300, env=env)
         assert "N=5324" in out.stdout
-        got[sampled] = [(tmp_path / "outputs" / "one_run" / f).read_bytes() for f in files]
-    for f, a, b in zip(files, got["1"], got["0"]):
-        assert a == b, f
+        got[sampled + async_io] = [(tmp_path / "outputs" / "one_run" / f).read_bytes() for f in files]
+    for other in ("01", "10"):
+        for f, a, b in zip(files, got["11"], got[other]):
+            assert a == b, (f, other)
     rows = io_formats.read_energies(tmp_path / "outputs" / "one_run" / "instantaneous_energies.dat")
     assert rows.shape == (3, 6) and np.all(np.isfinite(rows))
 
