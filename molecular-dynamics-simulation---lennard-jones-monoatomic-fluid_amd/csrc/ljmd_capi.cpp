@@ -333,7 +333,7 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
         n_wg = grid.x * grid.y;
     }
     if (q) LJMD_HIP(h, hipEventRecord(q->e[3], h->stream));
-    h->reduce_deferred = fast && h->fuse_tail && h->kick_hint >= 0 && n_wg <= 4096 && !needs_force_exchange(h);
+    h->reduce_deferred = fast && h->fuse_tail && h->kick_hint >= 0 && n_wg <= kDirectFoldMax && !needs_force_exchange(h);
     if (h->reduce_deferred) {            // the tail launch of enqueue_kick reduces, kicks and folds the record in one kernel
         h->deferred_nslab = nslab;
         h->deferred_n3 = n3;
@@ -416,7 +416,7 @@ int enqueue_kick(ljmd_t *h, bool kick, EventSet *q)
         LJMD_HIP(h, launch_finalize(h->pending_fold, nullptr, h->stream));
         h->fold_pending = false;
     }
-    if (h->fuse_small && h->pending_n_wg <= 4096) {
+    if (h->fuse_small && h->pending_n_wg <= kDirectFoldMax) {
         IntegrateArgs ia = integrate_args(h);
         ia.ticket = h->d_ticket;
         LJMD_HIP(h, launch_kick_finalize(ia, finalize_args(h, h->pending_n_wg, kick, h->pending_scale), kick, h->stream));
@@ -982,10 +982,10 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", plenty ? 131072 : kN3MidTargetItems));
         const int ns_wanted = (target_waves + h->NGo - 1) / h->NGo;
         int ns = std::max(1, std::min(ns_wanted, n_off));
-        // small single-rank systems: at most 4096 work items, so that the step record is folded by ONE block whichever
-        // way the step is launched (the fused step kernel keeps finalize_body's summation order, not fold_partials')
-        const bool small_single = n_ranks == 1 && n <= 8192 && rt <= 2;
-        const int ns_cap = small_single ? std::max(1, 4096 / std::max(1, h->NGo)) : n_units;
+        // small single-rank systems: at most kDirectFoldMax work items, so that the step record is folded by ONE block
+        // whichever way the step is launched (the fused step kernel keeps finalize_body's summation order, not fold_partials')
+        const bool small_single = n_ranks == 1 && n <= kFuseTailMaxN && rt <= kFuseTailMaxRowTiles;
+        const int ns_cap = small_single ? std::max(1, kDirectFoldMax / std::max(1, h->NGo)) : n_units;
         ns = std::min(ns, ns_cap);
         h->dchunk = (n_off + ns - 1) / ns;
         h->uchunk = h->dchunk * rt * parts;
@@ -996,7 +996,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         h->nslab_n = (n_units + h->uchunk - 1) / h->uchunk;
     }
     // two launches per step for small single-rank systems (tile_tail_kernel; ljmd_engine.h: fuse_tail)
-    h->fuse_tail = h->fuse_small && env_int("LJMD_FUSE_TAIL", 1) != 0 && n_ranks == 1 && n <= 8192 && h->rc_allows_fast &&
+    h->fuse_tail = h->fuse_small && env_int("LJMD_FUSE_TAIL", 1) != 0 && n_ranks == 1 && n <= kFuseTailMaxN && h->rc_allows_fast &&
                    precision_mode == LJMD_PRECISION_FP64 && (!h->use_n3 || (h->rt <= kFuseTailMaxRowTiles && h->wg_waves == 1));
     h->defer_record = env_int("LJMD_FUSE_DEFER_RECORD", 1) != 0;
     const bool mixed = precision_mode == LJMD_PRECISION_FP32_FORCE;

@@ -35,7 +35,8 @@ constexpr long kN3ItemsFor2 = 1000;     // ... or 2 (n >= 6144) tiles per row gr
 constexpr long kN3LargeItems = 131072;  // (row group, offset) pairs of a rank from which work items are slices of whole offsets
 constexpr int kN3MidTargetItems = 32768;   // work items aimed at below that (units of one pass, or of a part of one)
 constexpr int kBothTiesMaxGroups = 128; // row groups up to which the tie d = NG / 2 is worked from both sides
-constexpr int kFuseTailMaxRowTiles = 2; // tiles per row group up to which small systems take the two-launch step
+constexpr int kFuseTailMaxRowTiles = 2; // tiles per row group up to which small systems take the two-launch step ...
+constexpr int kFuseTailMaxN = 20000;    // ... and their largest particle count (n = 24 576: the in-kernel pass descriptors cost the pair kernel more than the launches save)
 constexpr int kMaxProfiledLaunches = 4096;
 constexpr int kEventsPerLaunch = 9;
 

@@ -26,6 +26,7 @@ constexpr unsigned kAllRows = (1u << kRowTiles) - 1u;
 constexpr int kSlotAlign = (kRowTiles * 64 > 256) ? kRowTiles * 64 : 256;   // P is a multiple of this
 constexpr int kPartialStride = 8;           // doubles per per-rank per-step partial record
 constexpr int kFoldBlocks = 128;             // pre-reduction blocks of the scalar partials (large grids)
+constexpr int kDirectFoldMax = 20480;        // workgroup partials up to which ONE block folds the step record (finalize_body) in every launch form
 constexpr int kBoxStride = 8;               // doubles per tile bounding box (lo xyz, hi xyz, 2 pad)
 
 struct PairArgs {
@@ -166,7 +167,7 @@ hipError_t launch_pair_n3_f32(const N3Args &a, dim3 grid, hipStream_t s);
 hipError_t launch_drift_kick(const IntegrateArgs &a, int phase /* 0 all, 1 positions, 2 velocities */, hipStream_t s);
 hipError_t launch_reduce_forces(const ReduceArgs &a, bool all_blocks, hipStream_t s);
 hipError_t launch_kick(const IntegrateArgs &a, bool kick, hipStream_t s);
-// kick + finalize in one launch: the last block to finish folds the partials (needs a.ticket, f.n_wg <= 4096)
+// kick + finalize in one launch: the last block to finish folds the partials (needs a.ticket, f.n_wg <= kDirectFoldMax)
 hipError_t launch_kick_finalize(const IntegrateArgs &a, const FinalizeArgs &f, bool kick, hipStream_t s);
 hipError_t launch_kinetic_fused(const IntegrateArgs &a, hipStream_t s);
 // out[i] = blocks[0][i] + blocks[1][i] + ... + blocks[G-1][i], i < len (left to right: the order is part of the result)

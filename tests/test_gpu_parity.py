@@ -963,7 +963,8 @@ def test_config2_10000_steps_vs_the_references_own_series():
     assert abs(Pm / Pr - 1.0) < 2e-2
 
 
-@pytest.mark.parametrize("n,knobs", [(108, {}), (500, {}), (3000, {}), (4096, {}), (5000, {}), (8192, {}), (32768, {}),
+@pytest.mark.parametrize("n,knobs", [(108, {}), (500, {}), (3000, {}), (4096, {}), (5000, {}), (8192, {}), (16384, {}), (20000, {}),
+                                     (32768, {}),
                                      (4096, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_PARTS": "2"}),
                                      (5000, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_PARTS": "1"}),
                                      (8192, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_PARTS": "4"}),
@@ -971,7 +972,7 @@ def test_config2_10000_steps_vs_the_references_own_series():
                                      (2000, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_PARTS": "2", "LJMD_N3_MIN_N": "1"})])
 def test_fused_launches_are_bitwise_equal_to_the_separate_kernels(n, knobs, monkeypatch):
     """LJMD_FUSE=1 (default): tile boxes written by the drift kernel, finalize folded into the kick kernel through
-    a last-block ticket -- and, for single-rank systems of up to 8192 particles (LJMD_FUSE_TAIL), a step in TWO launches:
+    a last-block ticket -- and, for single-rank systems of up to 20 000 particles (LJMD_FUSE_TAIL), a step in TWO launches:
     the pair kernel working its pass descriptors out itself, and tile_tail_kernel (slab reduction + kick + step record +
     the next step's drift / wrap / half-kick / boxes, one block per tile); below 4096 particles the gather kernel works
     its mask words out itself; and inside a batch the step record is folded by the NEXT tail launch
