@@ -294,7 +294,15 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
             //  0 of 4 at n = 262144 -- the mapping still saves 4.7 % (tools/probe_rank.py), with 128 it is neutral, as it
             //  is for single-rank systems of 16384..65536 particles)
             na.xcd_remap = (h->xcd_remap > 0 && (int)grid.x >= kXcdMinGroups && grid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
-            LJMD_HIP(h, launch_pair_n3(na, grid, h->wg_waves, h->stream));            // all pairs, or the NEAR ones
+            // mixed precision: the two pair kernels write disjoint slabs and partials -- the far pass (the long one) goes to
+            // its own stream first and the near pass, mostly descriptor look-ups with a few passes between them, runs beside it
+            const bool far_beside = h->mode == LJMD_PRECISION_FP32_FORCE && h->far_stream != nullptr;
+            if (far_beside) {
+                LJMD_HIP(h, hipEventRecord(h->ev_far_go, h->stream));
+                LJMD_HIP(h, hipStreamWaitEvent(h->far_stream, h->ev_far_go, 0));
+            } else {
+                LJMD_HIP(h, launch_pair_n3(na, grid, h->wg_waves, h->stream));        // all pairs, or the NEAR ones
+            }
             nslab = h->nslab_n;
             n_wg = grid.x * grid.y * h->wg_waves;                                      // one partial per wave
             n3 = true;
@@ -312,7 +320,12 @@ int enqueue_pair_forces(ljmd_t *h, EventSet *q)
                                                          // (CS2 = Dmax + 1) on one rank, the row group on several (CS2 = NGo)
                 fa.xcd_remap = (h->xcd_remap > 0 && (int)fgrid.x >= kXcdMinGroups && fgrid.x % (8 * h->xcd_remap) == 0) ? h->xcd_remap : 0;
                 fa.wg_part = h->d_wg_part + 2 * (size_t)n_wg;
-                LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, h->stream));
+                LJMD_HIP(h, launch_pair_n3_f32(fa, fgrid, far_beside ? h->far_stream : h->stream));
+                if (far_beside) {
+                    LJMD_HIP(h, hipEventRecord(h->ev_far_done, h->far_stream));
+                    LJMD_HIP(h, launch_pair_n3(na, grid, h->wg_waves, h->stream));    // the NEAR pairs, beside the far pass
+                    LJMD_HIP(h, hipStreamWaitEvent(h->stream, h->ev_far_done, 0));
+                }
                 nslab *= 2;
                 n_wg += fgrid.x * fgrid.y;
             }
@@ -576,6 +589,12 @@ void release(ljmd_t *h)
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) (void)ncclCommDestroy(h->comm);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->far_stream) {
+        (void)hipStreamSynchronize(h->far_stream);
+        (void)hipStreamDestroy(h->far_stream);
+    }
+    if (h->ev_far_go) (void)hipEventDestroy(h->ev_far_go);
+    if (h->ev_far_done) (void)hipEventDestroy(h->ev_far_done);
     if (h->ev_pos_ready) (void)hipEventDestroy(h->ev_pos_ready);
     if (h->ev_gather_done) (void)hipEventDestroy(h->ev_gather_done);
     for (auto &q : h->ev_pool)
@@ -1039,6 +1058,11 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
             if (h->rt == kRowTiles && h->wg_waves == 1 && h->parts == 1 && env_int("LJMD_N3_CLUSTERS", 1) != 0)
                 LJMD_HIP(h, hipMalloc(&h->d_desc2, (size_t)h->NGo * h->T * 8 * sizeof(float)));
             LJMD_HIP(h, hipMalloc(&h->d_pos_tc, P3 * h->G));
+        }
+        if (mixed && env_int("LJMD_FP32_FAR_STREAM", 1) != 0) {
+            LJMD_HIP(h, hipStreamCreateWithFlags(&h->far_stream, hipStreamNonBlocking));
+            LJMD_HIP(h, hipEventCreateWithFlags(&h->ev_far_go, hipEventDisableTiming));
+            LJMD_HIP(h, hipEventCreateWithFlags(&h->ev_far_done, hipEventDisableTiming));
         }
         if (mixed) {
             LJMD_HIP(h, hipMalloc(&h->d_mask_far, (size_t)h->TB * h->W * sizeof(uint64_t)));

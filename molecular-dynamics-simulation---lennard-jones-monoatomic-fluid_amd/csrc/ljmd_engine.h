@@ -178,6 +178,9 @@ struct ljmd {
 
     // asynchronous snapshot (ljmd_snapshot_begin/end): device copy of r, ru, v, a [4][3][P] + perm [P],
     // its pinned host mirror, the second stream that carries the HBM -> host transfer
+    // mixed precision: the fp32 far pass runs on its own stream beside the fp64 near pass (LJMD_FP32_FAR_STREAM, default on)
+    hipStream_t far_stream = nullptr;
+    hipEvent_t ev_far_go = nullptr, ev_far_done = nullptr;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_snap_ready = nullptr, ev_snap_done = nullptr;
     double *d_snap = nullptr, *h_snap = nullptr;
