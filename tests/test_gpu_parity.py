@@ -600,6 +600,19 @@ def test_mixed_precision_very_far_passes_keep_the_force_bits(monkeypatch):
     dev = np.abs(out["1"][0] - out["0"][0]) / np.abs(out["0"][0])
     print("very far passes: relative change of epot, d_epot, dd_epot", dev)
     assert 0.0 < dev.max() <= 1e-11
+    # the far pass on the engine's own stream instead of beside the near pass (LJMD_FP32_FAR_STREAM=0): same launches, same bits
+    monkeypatch.setenv("LJMD_FP32_FAR_STREAM", "0")
+    with Engine(p, precision_mode=_lib.PRECISION_FP32_FORCE) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        sc = np.array(eng.compute_forces())
+        a = np.stack(eng.get_state(("a",))["a"])
+        ser = np.stack(eng.verlet_steps(3))
+    monkeypatch.delenv("LJMD_FP32_FAR_STREAM")
+    with Engine(p, precision_mode=_lib.PRECISION_FP32_FORCE) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        eng.compute_forces()
+        ser2 = np.stack(eng.verlet_steps(3))
+    assert np.array_equal(sc, out["1"][0]) and np.array_equal(a, out["1"][1]) and np.array_equal(ser, ser2)
 
 
 def test_mixed_precision_energy_series_vs_oracle_n16384(oracle):
