@@ -997,7 +997,9 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         // (one pass, or one part of a pass) per item.
         const int n_off = h->Dmax + h->wg_waves;          // offsets a workgroup walks (relative to its first row group)
         const int n_units = n_off * rt * parts;
-        const bool plenty = (long)h->NGo * n_off >= kN3LargeItems;
+        // (a rank of a multi-rank run always aims at 131 072: its kernel is 1 / G of a large system's, measured best with the
+        //  most items -- profiles/r02_per_rank_xcd_threshold_and_target_waves.txt, r04_per_rank_work_items.txt)
+        const bool plenty = (long)h->NGo * n_off >= kN3LargeItems || n_ranks > 1;
         const int target_waves = std::max(1, env_int("LJMD_N3_TARGET_WAVES", plenty ? 131072 : kN3MidTargetItems));
         const int ns_wanted = (target_waves + h->NGo - 1) / h->NGo;
         int ns = std::max(1, std::min(ns_wanted, n_off));
