@@ -904,7 +904,11 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
     // Small systems (n <= 8192): one re-sort is ~30 launches = 135 us against a 33 us step, and in 200 steps a particle of
     // the liquid moves ~0.5 sigma against tiles of 4.3 sigma: every 200 steps (20: 25 300 steps/s at n = 4096, 100: 29 500,
     // 200: 30 000, 400: 30 500 -- tools/small_n_rate.py, profiles/r03_small_n_two_launch_step.txt).
-    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", n >= 1000000 ? 5 : n >= 131072 ? 10 : n > 8192 ? 20 : 200));
+    // Round 4 (profiles/r04_resort_interval_mid_n.txt): the same holds up to the end of the two-launch regime -- n = 12 288:
+    // 8225 steps/s at 20, 8929 at 200; 16 384: 5875 / 6130 -- where nearly every tile pair is inside the cutoff anyway; 50 up
+    // to 40 000 (32 768: 2134 / 2158), 20 beyond (65 536: 657 at 20, 645 at 200).
+    h->resort_every = std::max(1, env_int("LJMD_RESORT_EVERY", n >= 1000000 ? 5 : n >= 131072 ? 10 : n > 40000 ? 20
+                                                                   : n > kFuseTailMaxN ? 50 : 200));
     std::vector<int> kd_offsets;
     {   // k-d levels: segments = runs of whole tiles, halved until every segment is one tile
         const int tiles = (h->S + kTile - 1) / kTile;
