@@ -107,7 +107,6 @@ N3Args n3_args(ljmd_t *h)
     a.by_group = h->j_by_group;
     a.dchunk = h->dchunk;
     a.uchunk = h->uchunk;
-    a.parts_log2 = h->parts == 4 ? 2 : h->parts == 2 ? 1 : 0;
     a.xcd_remap = 0;
     a.inline_class = (h->fuse_tail && h->rt <= 2 && h->wg_waves == 1) ? 1 : 0;
     a.both_ties = h->both_ties ? 1 : 0;
@@ -977,19 +976,12 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         }
         if (rt != kRowTiles || h->NGo < 16 * wg) wg = 1;
         h->wg_waves = wg;
-        // parts per pass (N3Args::parts_log2): 2 or 4 cut the 64 rotation steps of a pass into independent work of 32 / 16 steps
-        // -- more, smaller work items for the systems that cannot fill 1024 SIMDs with whole passes.  One wave per workgroup
-        // only; not in the mixed mode (the far kernel walks whole passes over the same slices).
-        int parts = env_int("LJMD_N3_PARTS", 0);
-        if (parts != 1 && parts != 2 && parts != 4) parts = 1;
-        if (wg != 1 || mixed_mode) parts = 1;
-        h->parts = parts;
         // the tie d = NG / 2 worked from both sides (N3Args::both_ties): equal work for every row group where there are few
         // of them; one rank, one wave per workgroup, fp64 mode
         h->both_ties = wg == 1 && n_ranks == 1 && !mixed_mode && h->NG <= kBothTiesMaxGroups && env_int("LJMD_N3_BOTH_TIES", 1) != 0;
-        // slab_j: the blocks of a column tile lie together (N3Args::slab_j), `parts` of them per (row group | offset)
+        // slab_j: the blocks of a column tile lie together (N3Args::slab_j)
         h->j_by_group = (h->G > 1 || h->NG % wg != 0) ? 1 : 0;
-        h->CS = (h->j_by_group ? (h->NGo + wg - 1) / wg : (h->Dmax + wg - 1) / wg + 1) * parts;
+        h->CS = h->j_by_group ? (h->NGo + wg - 1) / wg : (h->Dmax + wg - 1) / wg + 1;
         h->CS2 = h->G > 1 ? h->NGo : h->Dmax + 1;              // far pass: one wave per workgroup
         const int n3_min = env_int("LJMD_N3_MIN_N", 4096);
         // (rc within 1e-9 of L/2 -- the reference accepts rc_over_L up to 0.5 and rejects only rc >= L/2 -- takes the exact
@@ -997,10 +989,9 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         //  rank must know that when it allocates)
         h->use_n3 = env_int("LJMD_N3", 1) != 0 && n >= n3_min && (h->G == 1 || h->rc_allows_fast);
         // work items = (row group, slice of its units), N3Args::uchunk.  Large systems: slices of whole offsets (dchunk),
-        // ~target_waves items; a system with fewer (row group, offset) pairs than that is cut finer, down to one unit
-        // (one pass, or one part of a pass) per item.
+        // ~target_waves items; a system with fewer (row group, offset) pairs than that is cut finer, down to one pass per item.
         const int n_off = h->Dmax + h->wg_waves;          // offsets a workgroup walks (relative to its first row group)
-        const int n_units = n_off * rt * parts;
+        const int n_units = n_off * rt;
         // (a rank of a multi-rank run always aims at 131 072: its kernel is 1 / G of a large system's, measured best with the
         //  most items -- profiles/r02_per_rank_xcd_threshold_and_target_waves.txt, r04_per_rank_work_items.txt)
         const bool plenty = (long)h->NGo * n_off >= kN3LargeItems || n_ranks > 1;
@@ -1013,8 +1004,8 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
         const int ns_cap = small_single ? std::max(1, kDirectFoldMax / std::max(1, h->NGo)) : n_units;
         ns = std::min(ns, ns_cap);
         h->dchunk = (n_off + ns - 1) / ns;
-        h->uchunk = h->dchunk * rt * parts;
-        if (!mixed_mode && (ns_wanted > n_off || parts > 1)) {          // finer than whole offsets
+        h->uchunk = h->dchunk * rt;
+        if (!mixed_mode && ns_wanted > n_off) {                          // finer than whole offsets
             const int nsu = std::max(1, std::min(std::min(ns_wanted, ns_cap), n_units));
             h->uchunk = (n_units + nsu - 1) / nsu;
         }
@@ -1061,7 +1052,7 @@ int ljmd_create(ljmd_t **out, int32_t n, double box_length, double dt, double rc
             LJMD_HIP(h, hipMemsetAsync(h->d_flag_j, 0, n_blk, h->stream));
             LJMD_HIP(h, hipMalloc(&h->d_desc, (size_t)h->NGo * h->T * sizeof(unsigned)));
             // cluster passes (ljmd_kernels.hip: n3_cluster_pass): 4-tile row groups, one wave per workgroup
-            if (h->rt == kRowTiles && h->wg_waves == 1 && h->parts == 1 && env_int("LJMD_N3_CLUSTERS", 1) != 0)
+            if (h->rt == kRowTiles && h->wg_waves == 1 && env_int("LJMD_N3_CLUSTERS", 1) != 0)
                 LJMD_HIP(h, hipMalloc(&h->d_desc2, (size_t)h->NGo * h->T * 8 * sizeof(float)));
             LJMD_HIP(h, hipMalloc(&h->d_pos_tc, P3 * h->G));
         }

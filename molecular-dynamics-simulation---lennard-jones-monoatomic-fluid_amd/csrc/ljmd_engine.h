@@ -33,7 +33,7 @@ constexpr int kMixedMinN = 16384;       // smallest system the mixed-precision m
 constexpr long kN3ItemsFor4 = 6000;     // (row group, offset) pairs a rank needs before 4 (n >= 32768 on one rank) ...
 constexpr long kN3ItemsFor2 = 1000;     // ... or 2 (n >= 6144) tiles per row group pay off: profiles/r04_unit_sweep.txt
 constexpr long kN3LargeItems = 131072;  // (row group, offset) pairs of a rank from which work items are slices of whole offsets
-constexpr int kN3MidTargetItems = 32768;   // work items aimed at below that (units of one pass, or of a part of one)
+constexpr int kN3MidTargetItems = 32768;   // work items aimed at below that on one rank (units of one pass)
 constexpr int kBothTiesMaxGroups = 128; // row groups up to which the tie d = NG / 2 is worked from both sides
 constexpr int kFuseTailMaxRowTiles = 2; // tiles per row group up to which small systems take the two-launch step ...
 constexpr int kFuseTailMaxN = 20000;    // ... and their largest particle count (n = 24 576: the in-kernel pass descriptors cost the pair kernel more than the launches save)
@@ -144,7 +144,7 @@ struct ljmd {
     bool use_n3 = false;
     int wg_waves = 1;                 // LJMD_N3_WG_WAVES: row groups (waves) per pair-kernel workgroup (1, 2, 4)
     bool both_ties = false;           // one rank, one wave per workgroup: the tie d = NG / 2 is worked from both sides (N3Args::both_ties)
-    int parts = 1, uchunk = 0;        // parts per pass (LJMD_N3_PARTS: 1, 2, 4) and units per work item (N3Args::uchunk)
+    int uchunk = 0;                   // units (passes) per work item (N3Args::uchunk)
     // two launches per step, record fold off the critical path (tile_tail_kernel): the step's record is folded by the NEXT
     // tail launch of the batch; the workgroup partials and per-tile v^2 sums it reads alternate between two buffers
     bool fold_pending = false, defer_record = true;

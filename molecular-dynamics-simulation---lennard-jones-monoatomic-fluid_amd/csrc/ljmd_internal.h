@@ -73,10 +73,8 @@ struct N3Args {
     int CS, by_group;       // slab_j layout (above)
     int RT;                 // tiles per row group: 4 for large systems, 1 or 2 to give small ones enough work items
     int dchunk;             // fp32 far kernel: offsets d per grid.y slice
-    int uchunk;             // pair_n3_kernel: UNITS per grid.y slice.  Unit u of a row group = (e * RT + l) * H + part: offset e,
-                            // column tile l of the group there, part of the pass; = dchunk * RT * H unless the system is cut finer
-    int parts_log2;         // H = 1 << parts_log2 = 1, 2 or 4 parts of 64 / H rotation steps per pass (one wave per workgroup
-                            // only); slab_j then holds H blocks per (column tile, row group or offset), CS counts them all
+    int uchunk;             // pair_n3_kernel: UNITS per grid.y slice.  Unit u of a row group = e * RT + l: offset e, column tile l of
+                            // the group there (one pass); = dchunk * RT unless the system is cut finer
     int energy;             // 0: forces only -- the energy sums are not accumulated and the workgroup partials are NaN
     int xcd_remap;          // C > 0: XCD-aware mapping, chunks of C consecutive row groups per XCD (gridDim.x % (8 C) == 0)
     int inline_class;       // RT <= 2, one wave per workgroup: the waves compute their pass descriptors themselves (desc unused)

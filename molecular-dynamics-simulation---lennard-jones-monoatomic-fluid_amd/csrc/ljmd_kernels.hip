@@ -461,9 +461,9 @@ __device__ __forceinline__ void column_tile_loop(const double (&xi)[RT], const d
                                                  double &jx, double &jy, double &jz, double &s12, double &s6)
 {
     static_assert(!BATCH || (!MASKED && (RT == 2 || RT == 4)), "batched reciprocal: all row tiles, 2 or 4 of them");
-    static_assert(kTile / 4 % LJMD_N3_UNROLL == 0, "a quarter pass is a whole number of unrolled bodies");
-    // The rotation steps s0 .. s0 + ns - 1 of the pass (a whole pass: 0 .. 63; a PART of one, N3Args::parts: a half or a
-    // quarter of them; ns is a multiple of the unroll count).  park = &lds[lane - s0]: entry (lane + 64 - s0 - s) is the
+    static_assert(kTile / 2 % LJMD_N3_UNROLL == 0, "half a pass is a whole number of unrolled bodies");
+    // The rotation steps s0 .. s0 + ns - 1 of the pass (a whole pass: 0 .. 63; one side of a tie worked from both sides,
+    // N3Args::both_ties: 0 .. 31 or 1 .. 32; ns is a multiple of the unroll count).  park = &lds[lane - s0]: entry (lane + 64 - s0 - s) is the
     // particle that step s0 + s brings to the lane (s0 + s = 0: the lane's own).
     double xj, yj, zj;
     double nx = park[kTile], ny = park[kLdsAxis + kTile], nz = park[2 * kLdsAxis + kTile];
@@ -957,44 +957,40 @@ __global__ __launch_bounds__(kTile * W, MIN_WAVES) void pair_n3_kernel(N3Args a)
     }
 
     // UNITS of work.  A row group walks the offsets e = 0 .. Dmax (+ W - 1: e is counted from the workgroup's FIRST row
-    // group, wave w is at its own offset d = e - w), at every offset the RT column tiles l of the group there, and every
-    // such pass in H = 1 << parts_log2 PARTS of 64 / H rotation steps: unit u = (e * RT + l) * H + part.  A work item
-    // (grid.y slice) takes `uchunk` consecutive units.  Large systems: H = 1 and uchunk = a few offsets' worth, one item is
-    // several whole passes; small and middle-sized ones cut finer -- down to a quarter pass per item -- so that the 1024
-    // SIMDs get several items each (profiles/r04_mid_n_rates.txt).
-    // Every wave of the workgroup runs the same units (one barrier per column tile when W > 1; then H = 1).
-    const int hl = W == 1 ? a.parts_log2 : 0, H = 1 << hl;
+    // group, wave w is at its own offset d = e - w) and at every offset the RT column tiles l of the group there: unit
+    // u = e * RT + l, one PASS.  A work item (grid.y slice) takes `uchunk` consecutive units.  Large systems: a few offsets'
+    // worth; small and middle-sized ones cut finer -- down to one pass per item -- so that the 1024 SIMDs get several items
+    // each (profiles/r04_unit_sweep.txt; cutting the passes themselves into halves or quarters was built, measured there and
+    // removed: a part repeats the item's fixed cost).  Every wave of the workgroup runs the same units (one barrier per
+    // column tile when W > 1).
     const int u0 = (int)by * a.uchunk;
-    const int nt = max(0, min(a.uchunk, (((a.Dmax + W) * RT) << hl) - u0));
+    const int nt = max(0, min(a.uchunk, (a.Dmax + W) * RT - u0));
     // The tie d = NG / 2 (NG even) is one pass for TWO row groups.  both_ties (one rank, W = 1): instead of one side owning
     // the whole pass and the other idling, A < B takes the steps 0 .. 31 against B and B the steps 1 .. 32 against A.  Step
     // s of (A, B) pairs row i with column i - s; step s' of (B, A) pairs row j with column j - s', i.e. the shift -s' of the
     // first pass: the two halves cover every shift mod 64 exactly once, and the work of the row groups is equal.
     const bool both = W == 1 && a.both_ties != 0;
 
-    // unit t of this work item: its column tile c, offset d, steps s0 .. s0 + ns - 1, slab block, and the mask bits of
+    // unit t of this work item: its column tile c, offset d, rotation steps s0 .. s0 + ns - 1, slab block, and the mask bits of
     // the wave's RT row tiles (0 = nothing to do: not owned, or every row tile proven outside the cutoff)
     auto tile_of = [&](int t, int &c, int &d, int &l, int &s0, int &ns, size_t &blk, unsigned &desc) -> unsigned {
-        const int u = u0 + t, pass = u >> hl, hp = u - (pass << hl);
-        const int e = pass / RT;
-        l = pass - e * RT;
+        const int u = u0 + t;
+        const int e = u / RT;
+        l = u - e * RT;
         d = e - wv;
         const bool valid = active && d >= 0 && d <= a.Dmax;
         int B = A0 + e;
         if (B >= a.NG) B -= a.NG;
         const bool tie = 2 * d == a.NG;
-        bool work = valid && ((d == 0) || (2 * d < a.NG) || (tie && (A < B || both)));
+        const bool work = valid && ((d == 0) || (2 * d < a.NG) || (tie && (A < B || both)));
         c = RT * B + l;                                 // column tile (global)
-        blk = (size_t)c * a.CS + (size_t)(((a.by_group ? (int)bx : e / W) << hl) + hp);   // N3Args::slab_j
-        ns = kTile >> hl;
-        s0 = hp * ns;
-        if (tie && both) {
-            const int side = A < B ? 0 : 1;
-            if (H == 1) { s0 = side; ns = kTile / 2; }
-            else if (2 * hp < H) s0 += side;
-            else work = false;
+        blk = (size_t)c * a.CS + (size_t)(a.by_group ? (int)bx : e / W);   // N3Args::slab_j
+        s0 = 0;
+        ns = kTile;
+        if (tie && both) {                              // the lower row group: steps 0 .. 31, the upper one: 1 .. 32
+            s0 = A < B ? 0 : 1;
+            ns = kTile / 2;
         }
-        if (RT == 1 && d == 0 && s0 > kTile / 2) work = false;     // a tile against itself ends with step 32
         unsigned mb = 0;
         desc = 0;
         if (work) {

@@ -54,19 +54,18 @@ def test_force_call_vs_reference_golden(golden, name, monkeypatch):
     check_force(sc, a, g)
 
 
-@pytest.mark.parametrize("parts", ["1", "2", "4"])
+@pytest.mark.parametrize("target", ["0", "1000000"])
 @pytest.mark.parametrize("row_tiles", ["1", "2", "4"])
 @pytest.mark.parametrize("name", ["force_n108", "force_n500", "force_n4000", "force_n4096"])
-def test_newton3_kernel_vs_reference_golden(golden, name, row_tiles, parts, monkeypatch):
+def test_newton3_kernel_vs_reference_golden(golden, name, row_tiles, target, monkeypatch):
     """The Newton-3 rotation kernel normally engages at N >= 4096; force it at the golden sizes in all three
-    instantiations (1, 2, 4 tiles per row group), with whole passes and with passes cut into 2 / 4 parts of 32 / 16
-    rotation steps (N3Args::parts_log2; one unit per work item).  With 4 tiles per group: N=108 -> one row group
-    (diagonal only), N=500 -> two groups (the d = NG/2 tie, worked from both sides), N=4000/4096 -> 16 groups, 9 offsets."""
+    instantiations (1, 2, 4 tiles per row group), with the library's own work items and with one pass per work item
+    (N3Args::uchunk = 1).  With 4 tiles per group: N=108 -> one row group (diagonal only), N=500 -> two groups (the
+    d = NG/2 tie, worked from both sides), N=4000/4096 -> 16 groups, 9 offsets."""
     monkeypatch.setenv("LJMD_N3_MIN_N", "1")
     monkeypatch.setenv("LJMD_N3_ROW_TILES", row_tiles)
-    monkeypatch.setenv("LJMD_N3_PARTS", parts)
-    if parts != "1":
-        monkeypatch.setenv("LJMD_N3_TARGET_WAVES", "1000000")
+    if target != "0":
+        monkeypatch.setenv("LJMD_N3_TARGET_WAVES", target)
     g = golden(name)
     n = int(g["n"])
     p = init_params(n, float(g["L"]), 0.005, float(g["rc"]))
@@ -978,11 +977,9 @@ def test_config2_10000_steps_vs_the_references_own_series():
 
 @pytest.mark.parametrize("n,knobs", [(108, {}), (500, {}), (3000, {}), (4096, {}), (5000, {}), (8192, {}), (16384, {}), (20000, {}),
                                      (32768, {}),
-                                     (4096, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_PARTS": "2"}),
-                                     (5000, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_PARTS": "1"}),
-                                     (8192, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_PARTS": "4"}),
-                                     (4096, {"LJMD_N3_ROW_TILES": "1", "LJMD_N3_PARTS": "2"}),
-                                     (2000, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_PARTS": "2", "LJMD_N3_MIN_N": "1"})])
+                                     (4096, {"LJMD_N3_ROW_TILES": "2"}), (5000, {"LJMD_N3_ROW_TILES": "2"}),
+                                     (8192, {"LJMD_N3_ROW_TILES": "1"}),
+                                     (2000, {"LJMD_N3_ROW_TILES": "2", "LJMD_N3_MIN_N": "1"})])
 def test_fused_launches_are_bitwise_equal_to_the_separate_kernels(n, knobs, monkeypatch):
     """LJMD_FUSE=1 (default): tile boxes written by the drift kernel, finalize folded into the kick kernel through
     a last-block ticket -- and, for single-rank systems of up to 20 000 particles (LJMD_FUSE_TAIL), a step in TWO launches:
@@ -991,7 +988,7 @@ def test_fused_launches_are_bitwise_equal_to_the_separate_kernels(n, knobs, monk
     its mask words out itself; and inside a batch the step record is folded by the NEXT tail launch
     (LJMD_FUSE_DEFER_RECORD).  Same values, same reductions, same order -> the same bits as the separate launches,
     sampled (forces-only) segments included."""
-    for k, val in knobs.items():               # two-tile row groups (one tail block per group) / passes cut into parts
+    for k, val in knobs.items():               # two-tile row groups (one tail block per group) where the library takes one, and back
         monkeypatch.setenv(k, val)
     p, r, v = synthetic.make_config(n, seed=9)
     out = []
@@ -1109,17 +1106,16 @@ def test_lds_combining_workgroups_equal_one_wave_per_workgroup(wg, n, monkeypatc
     assert np.abs(wa[1] - ao).max() <= REL_ACCEL * np.abs(ao).max()
 
 
-@pytest.mark.parametrize("n,row_tiles,parts,target,both", [
-    (20000, "4", "2", "1000000", "1"), (20000, "4", "4", "20000", "1"), (20000, "2", "2", "1000000", "1"),
-    (16384, "4", "4", "1000000", "1"), (16384, "4", "1", "1000000", "1"), (16384, "4", "1", "1000000", "0"),
-    (16384, "2", "4", "30000", "1"), (12288, "1", "2", "1000000", "1"), (12288, "1", "1", "1000000", "0"),
-    (5000, "2", "2", "1000000", "1"), (5000, "1", "4", "1000000", "1")])
-def test_passes_cut_into_parts_equal_whole_passes(n, row_tiles, parts, target, both, monkeypatch, oracle):
-    """Work items finer than whole offsets (N3Args::uchunk, parts_log2): one pass, or a half / a quarter of its 64 rotation
-    steps, per work item, the tie d = NG / 2 worked from both sides (both_ties) or by its lower row group.  Same pairs,
-    another summation tree: against whole passes in slices of offsets to rounding, against the oracle within the usual
-    bounds, a 25-step trajectory (crosses a re-sort), run-to-run bitwise.  n = 20000 and 5000 leave a partially filled last
-    tile and row group; 16384 / 4 tiles and 12288 / 1 tile have an even number of row groups (a tie)."""
+@pytest.mark.parametrize("n,row_tiles,target,both", [
+    (20000, "4", "1000000", "1"), (20000, "4", "20000", "1"), (20000, "2", "1000000", "1"),
+    (16384, "4", "1000000", "1"), (16384, "4", "1000000", "0"), (16384, "2", "30000", "1"),
+    (12288, "1", "1000000", "1"), (12288, "1", "1000000", "0"), (5000, "2", "1000000", "1"), (5000, "1", "1000000", "1")])
+def test_single_pass_work_items_equal_slices_of_offsets(n, row_tiles, target, both, monkeypatch, oracle):
+    """Work items finer than whole offsets (N3Args::uchunk): down to ONE pass per work item, the tie d = NG / 2 worked from
+    both sides (both_ties: the steps 0 .. 31 by the lower row group, 1 .. 32 by the upper one) or by its lower row group.
+    Same pairs, another summation tree: against one work item per row group to rounding, against the oracle within the
+    usual bounds, a 25-step trajectory (crosses a re-sort), run-to-run bitwise.  n = 20000 and 5000 leave a partially filled
+    last tile and row group; 16384 / 4 tiles and 12288 / 1 tile have an even number of row groups (a tie)."""
     monkeypatch.setenv("LJMD_N3_ROW_TILES", row_tiles)
     monkeypatch.setenv("LJMD_FUSE_TAIL", "0")
     p, r, v = synthetic.make_config(n, seed=19)
@@ -1127,9 +1123,9 @@ def test_passes_cut_into_parts_equal_whole_passes(n, row_tiles, parts, target, b
     e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, r[0].copy(), r[1].copy(), r[2].copy())
     ao = np.stack([ax, ay, az])
     out = {}
-    for key, knobs in (("whole", {"LJMD_N3_PARTS": "1", "LJMD_N3_TARGET_WAVES": "1", "LJMD_N3_BOTH_TIES": "0"}),
-                       ("cut", {"LJMD_N3_PARTS": parts, "LJMD_N3_TARGET_WAVES": target, "LJMD_N3_BOTH_TIES": both}),
-                       ("cut2", {"LJMD_N3_PARTS": parts, "LJMD_N3_TARGET_WAVES": target, "LJMD_N3_BOTH_TIES": both})):
+    for key, knobs in (("whole", {"LJMD_N3_TARGET_WAVES": "1", "LJMD_N3_BOTH_TIES": "0"}),
+                       ("cut", {"LJMD_N3_TARGET_WAVES": target, "LJMD_N3_BOTH_TIES": both}),
+                       ("cut2", {"LJMD_N3_TARGET_WAVES": target, "LJMD_N3_BOTH_TIES": both})):
         for k, val in knobs.items():
             monkeypatch.setenv(k, val)
         with Engine(p) as eng:

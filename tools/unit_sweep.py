@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Work-item shapes of the Newton-3 pair kernel for single-rank systems: tiles per row group (LJMD_N3_ROW_TILES) x parts per
-pass (LJMD_N3_PARTS) x work items aimed at (LJMD_N3_TARGET_WAVES), in the liquid (200 steps from the jittered lattice).
+pass (LJMD_N3_PARTS: read only by the round-4 measurement builds, the knob is no longer in the tree) x work items aimed at
+(LJMD_N3_TARGET_WAVES), in the liquid (200 steps from the jittered lattice).
 Prints step rate and the pair kernel's min / median launch (HIP events).  Measurement tool.
 usage: unit_sweep.py n [rt,parts,target ...]      ("0,0,0" = the library's own choice)"""
 import os
