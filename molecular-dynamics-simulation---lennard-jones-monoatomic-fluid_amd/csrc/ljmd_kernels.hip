@@ -2056,7 +2056,7 @@ __global__ __launch_bounds__(kBlock * TPB) void tile_tail_kernel(ReduceArgs ra, 
     // the terms q, q + 4, ...  A block that was not written this step (flag 0) adds an exact zero here instead of being
     // skipped -- s + 0.0 == s -- so that the loads do not depend on the flags and are in flight together: the chain of
     // ~17 dependent load-and-add round trips per wave was half of this kernel's 17 us at n = 4096.
-#pragma unroll 4
+#pragma unroll 8
     for (int c = q; c < ra.nslab; c += kWavesPerBlock) {
         const double *sl = ra.slab + (size_t)c * 3 * ra.P + i;
         s[0] += sl[0];
@@ -2065,7 +2065,7 @@ __global__ __launch_bounds__(kBlock * TPB) void tile_tail_kernel(ReduceArgs ra, 
     }
     if constexpr (N3) {
         // the tile's CS blocks, contiguous (N3Args::slab_j)
-#pragma unroll 4
+#pragma unroll 8
         for (int j = q; j < ra.CS; j += kWavesPerBlock) {
             const size_t blk = (size_t)tile * ra.CS + j;
             const bool on = ra.flag_j[blk] != 0;
