@@ -2002,7 +2002,7 @@ __global__ __launch_bounds__(kBlock) void kick_finalize_kernel(IntegrateArgs a, 
 // its dependent launches -- five kernels of 4-19 us at n = 4096 -- not by any of them.  tile_tail_kernel is everything
 // behind the pair kernel AND, inside a batch of steps, the next step's K1, one 256-thread block per tile:
 //   K3a  the tile's partial accelerations, the four waves splitting the terms as reduce_forces_kernel does;
-//   K3b  x24, second half-kick, sum v^2 per tile (wave 0; lj_potential_energy.f90:189-191, verlet.f90:86-95);
+//   K3b  x24, second half-kick, sum v^2 per tile (waves 0 .. 2: one axis each; lj_potential_energy.f90:189-191, verlet.f90:86-95);
 //   K1'  DRIFT: the NEXT step's drift + wrap + first half-kick + unwrapped update of the tile's 64 particles
 //        (verlet.f90:58-74, md_simulation_program.f90:341-351 -- a particle's K1 reads only its own r, v, a), the tile's
 //        coherent copy and its bounding box, as drift_kick_kernel<0, true> writes them;
@@ -2019,8 +2019,8 @@ __global__ __launch_bounds__(kBlock) void kick_finalize_kernel(IntegrateArgs a, 
 // before and its last block folds the pending record, then its own.  Records are appended in step order either way.
 // TPB = tiles per block = tiles per Newton-3 row group (1, or 2: pair_n3_kernel<., 2, .> for small systems): the block's
 // 4 TPB waves reduce TPB consecutive tiles side by side (wave 4 b + q = tile b's terms q, q + 4, ...: the split and the
-// order of the one-tile form), then wave 0 integrates them one after the other -- the tiles of a row group share the
-// frame of their coherent copy (its first particle: tile_boxes_kernel), so the second tile needs the first one's result.
+// order of the one-tile form), then three waves of every tile integrate its three axes -- the tiles of a row group share
+// the frame of their coherent copy (its first particle: tile_boxes_kernel), so the second tile takes the first one's anchor.
 template <bool N3, bool KICK, bool DRIFT, int TPB>
 __global__ __launch_bounds__(kBlock * TPB) void tile_tail_kernel(ReduceArgs ra, IntegrateArgs a, FinalizeArgs f, FinalizeArgs prev)
 {
@@ -2035,21 +2035,16 @@ __global__ __launch_bounds__(kBlock * TPB) void tile_tail_kernel(ReduceArgs ra, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = wave & (kWavesPerBlock - 1), tb = wave / kWavesPerBlock;
     const int tile = blockIdx.x * TPB + tb;
     const int i = tile * kTile + lane;                          // slot
-    // wave 0 integrates the tiles behind the reduction: its loads go out first and arrive while the partial sums are formed
-    double v_in[TPB][3], r_in[TPB][3], ru_in[TPB][3];
-    if (wave == 0) {
-#pragma unroll
-        for (int b = 0; b < TPB; ++b)
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                const size_t o = (size_t)ax * a.P + i + b * kTile;
-                v_in[b][ax] = r_in[b][ax] = ru_in[b][ax] = 0.0;
-                if constexpr (KICK || DRIFT) v_in[b][ax] = a.v[o];
-                if constexpr (DRIFT) {
-                    r_in[b][ax] = a.r[o];
-                    ru_in[b][ax] = a.ru[o];
-                }
-            }
+    // behind the reduction the waves q = 0, 1, 2 of a tile integrate its x, y, z (a particle's K3b / K1 arithmetic, the tile's
+    // frame, box and sum v^2 are all per axis): their loads go out first and arrive while the partial sums are formed
+    double v_in = 0.0, r_in = 0.0, ru_in = 0.0;
+    if (q < 3) {
+        const size_t o = (size_t)q * a.P + i;
+        if constexpr (KICK || DRIFT) v_in = a.v[o];
+        if constexpr (DRIFT) {
+            r_in = a.r[o];
+            ru_in = a.ru[o];
+        }
     }
     double s[3] = {0.0, 0.0, 0.0};
     // The order of reduce_forces_kernel (single rank): the row-side slices, then the column-side blocks, wave q taking
@@ -2080,63 +2075,61 @@ __global__ __launch_bounds__(kBlock * TPB) void tile_tail_kernel(ReduceArgs ra, 
     part[wave][1][lane] = s[1];
     part[wave][2][lane] = s[2];
     __syncthreads();
-    if (wave == 0) {
-        double anchor[3] = {0.0, 0.0, 0.0};                     // the row group's frame: its first tile's first particle
+    __shared__ double anchor_s[3];                              // the row group's frame: its first tile's first particle
+    double rn = 0.0;
+    if (q < 3) {
+        const int ax = q;
+        double t = part[kWavesPerBlock * tb][ax][lane];
 #pragma unroll
-        for (int b = 0; b < TPB; ++b) {
-            double k2[3] = {0.0, 0.0, 0.0}, rn[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                double t = part[kWavesPerBlock * b][ax][lane];
-#pragma unroll
-                for (int w = 1; w < kWavesPerBlock; ++w) t += part[kWavesPerBlock * b + w][ax][lane];
-                const size_t o = (size_t)ax * a.P + i + b * kTile;
-                const double acc = 24.0 * t;                        // kick_kernel
-                a.a[o] = acc;
-                double vel = v_in[b][ax];
-                if constexpr (KICK) {
-                    vel = vel + acc * a.dt_half;
-                    k2[ax] = vel * vel;
-                }
-                if constexpr (DRIFT) {                              // drift_kick_kernel<0> of the next step
-                    const double r0 = r_in[b][ax];
-                    double r1 = (r0 + vel * a.dt) + acc * a.dt_sq_half;
-                    r1 = r1 - a.L * __builtin_floor(r1 * a.invL);
-                    double d = r1 - r0;
-                    d = d - a.L * __builtin_round(d * a.invL);
-                    a.r[o] = r1;
-                    a.ru[o] = ru_in[b][ax] + d;
-                    rn[ax] = r1;
-                    vel = vel + acc * a.dt_half;
-                }
-                if constexpr (KICK || DRIFT) a.v[o] = vel;
+        for (int w = 1; w < kWavesPerBlock; ++w) t += part[kWavesPerBlock * tb + w][ax][lane];
+        const size_t o = (size_t)ax * a.P + i;
+        const double acc = 24.0 * t;                            // kick_kernel
+        a.a[o] = acc;
+        double vel = v_in, k2 = 0.0;
+        if constexpr (KICK) {
+            vel = vel + acc * a.dt_half;
+            k2 = vel * vel;
+        }
+        if constexpr (DRIFT) {                                  // drift_kick_kernel<0> of the next step
+            const double r0 = r_in;
+            double r1 = (r0 + vel * a.dt) + acc * a.dt_sq_half;
+            r1 = r1 - a.L * __builtin_floor(r1 * a.invL);
+            double d = r1 - r0;
+            d = d - a.L * __builtin_round(d * a.invL);
+            a.r[o] = r1;
+            a.ru[o] = ru_in + d;
+            rn = r1;
+            vel = vel + acc * a.dt_half;
+        }
+        if constexpr (KICK || DRIFT) a.v[o] = vel;
+        if constexpr (KICK) {
+            const double ks = wave_sum(k2);
+            if (lane == 0) const_cast<double *>(f.ke_tile)[3 * (size_t)tile + ax] = ks;
+        }
+    }
+    if constexpr (DRIFT) {
+        if (a.pos_tc) {                                         // tile frame: the block is the row group
+            double anchor = wave_first(rn);
+            if constexpr (TPB > 1) {                            // the group's later tiles take the first one's anchor
+                if (q < 3 && tb == 0 && lane == 0) anchor_s[q] = anchor;
+                __syncthreads();
+                if (q < 3) anchor = anchor_s[q];
             }
-            if constexpr (KICK) {
-                const double kx = wave_sum(k2[0]), ky = wave_sum(k2[1]), kz = wave_sum(k2[2]);
-                if (lane == 0) {
-                    double *w = const_cast<double *>(f.ke_tile) + 3 * (size_t)(tile + b);
-                    w[0] = kx; w[1] = ky; w[2] = kz;
-                }
+            if (q < 3) {
+                rn = tile_frame(rn, anchor, a.L, a.invL);
+                a.pos_tc[(size_t)q * a.P + i] = rn;
             }
-            if constexpr (DRIFT) {
-                if (a.pos_tc) {                                     // tile frame: the block is the row group
-#pragma unroll
-                    for (int ax = 0; ax < 3; ++ax) {
-                        if (b == 0) anchor[ax] = wave_first(rn[ax]);
-                        rn[ax] = tile_frame(rn[ax], anchor[ax], a.L, a.invL);
-                        a.pos_tc[(size_t)ax * a.P + i + b * kTile] = rn[ax];
-                    }
-                }
-                const double lx = wave_min(rn[0]), ly = wave_min(rn[1]), lz = wave_min(rn[2]);
-                const double hx = wave_max(rn[0]), hy = wave_max(rn[1]), hz = wave_max(rn[2]);
-                if (lane == 0) {
-                    double *o = a.bbox + (size_t)(tile + b) * kBoxStride;
-                    o[0] = lx; o[1] = ly; o[2] = lz;
-                    o[3] = hx; o[4] = hy; o[5] = hz;
-                }
+        }
+        if (q < 3) {
+            const double lo = wave_min(rn), hi = wave_max(rn);
+            if (lane == 0) {
+                double *o = a.bbox + (size_t)tile * kBoxStride;
+                o[q] = lo;
+                o[3 + q] = hi;
             }
         }
     }
+    __syncthreads();                                       // the three waves' stores are out before thread 0 fences and draws the ticket
     if (threadIdx.x >= kBlock) return;                     // (the record is folded by 256 threads: finalize_body)
     if (!a.ticket) return;                                 // this step's record: the next launch's extra block
     if (threadIdx.x == 0) {
