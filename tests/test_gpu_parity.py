@@ -178,6 +178,36 @@ def test_tiles_that_straddle_a_box_face_vs_oracle_n32768(oracle, mode, monkeypat
         assert np.abs(a - a_o).max() <= 1e-9 * np.abs(a_o).max()
 
 
+def test_liquid_state_forces_vs_oracle_n65536(oracle):
+    """One force evaluation in the equilibrated LIQUID (300 steps from the jittered lattice: about a fifth of the passes with a
+    straddling axis, boundary passes cluster by cluster, rc = 21.3 sigma so that the fp32 far kernel has very far passes, most
+    of them next to passes that are not) against the pinned oracle on every particle at the engine's own wrapped positions:
+    fp64 at the single-call bounds, then the same configuration in the mixed-precision mode at its written bounds."""
+    from ljmd_amd import _lib
+    n = 65536
+    p, r, v = synthetic.make_config(n, seed=23)
+    with Engine(p) as eng:
+        eng.set_state(r[0], r[1], r[2], v[0], v[1], v[2])
+        eng.compute_forces()
+        e, k, d, dd = eng.verlet_steps(300)
+        st = eng.get_state(("r", "v", "a"))
+    rr, vv, a = np.stack(st["r"]), np.stack(st["v"]), np.stack(st["a"])
+    po = oracle.derive_params(n, p.box_length, p.dt, p.rc)
+    e_o, d_o, dd_o, ax, ay, az = oracle.compute_forces(po, rr[0].copy(), rr[1].copy(), rr[2].copy())
+    a_o = np.stack([ax, ay, az])
+    assert rel(e[-1], e_o) <= 1e-12 and rel(d[-1], d_o) <= 1e-12 and rel(dd[-1], dd_o) <= 1e-12
+    assert np.abs(a - a_o).max() <= REL_ACCEL * np.abs(a_o).max()
+    with Engine(p, precision_mode=_lib.PRECISION_FP32_FORCE) as eng:
+        eng.set_state(rr[0], rr[1], rr[2], vv[0], vv[1], vv[2])
+        em, dm, ddm = eng.compute_forces()
+        am = np.stack(eng.get_state(("a",))["a"])
+    # (cutoff-edge pairs, see test_mixed_precision_far_pass_beside_lds_combining_workgroups: 24 rc^-7 = 1.2e-8 at rc = 21.3)
+    edge = 24.0 * abs(p.rc ** -7 - 2.0 * p.rc ** -13)
+    print("liquid n = 65536, mixed vs oracle:", rel(em, e_o), rel(dm, d_o), rel(ddm, dd_o), np.abs(am - a_o).max() / np.abs(a_o).max())
+    assert rel(em, e_o) <= 5e-9 and rel(dm, d_o) <= 5e-9 and rel(ddm, dd_o) <= 5e-9
+    assert np.abs(am - a_o).max() <= 1e-9 * np.abs(a_o).max() + 2.0 * edge
+
+
 @pytest.mark.parametrize("n,rc_over_L,n3", [(4096, 0.15, True), (4096, 0.15, False), (32768, 0.08, True), (2500, 0.30, True)])
 def test_short_cutoff_most_tile_pairs_skipped(oracle, n, rc_over_L, n3, monkeypatch):
     """rc well below L/2 (allowed by the reference: 0 < rc_over_L <= 0.5): most tile pairs are masked
